@@ -1,0 +1,100 @@
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference) is imported unmodified; weights are our own
+seeded synthetic tensors (underwater_image_restoration_amd.synth), loaded via
+``load_state_dict(strict=True)`` so the key/shape listing is checked too.
+Only inputs' seeds and (sub-sampled) outputs are stored; the reference's
+source never enters this repository.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from underwater_image_restoration_amd.synth import (student_param_shapes, synth_state_dict,  # noqa: E402
+                                                    synth_student_inputs)
+from tests.golden.cases import STUDENT_CASES, compress  # noqa: E402
+
+
+def student_case(name: str, cfg: dict) -> None:
+    from underwater_ir.student.naf_unet_wfi import NAFNetWFIGate
+
+    mk = dict(base_channels=cfg["base_channels"], num_levels=3, blocks_per_level=cfg["blocks_per_level"],
+              cond_dim=cfg["cond_dim"], num_masks=cfg["num_masks"], num_degradation_types=cfg["num_deg"])
+    model = NAFNetWFIGate(**mk).eval()
+    shapes = student_param_shapes(**mk)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert set(ref_shapes.keys()) == set(shapes.keys()), "state_dict key-name mismatch"
+    assert ref_shapes == dict(shapes), "state_dict shape mismatch"
+    sd = synth_state_dict(shapes, seed=cfg["wseed"])
+    model.load_state_dict(sd, strict=True)
+    x, z, m = synth_student_inputs(cfg["batch"], cfg["H"], cfg["W"], cfg["cond_dim"], cfg["num_masks"],
+                                   mask_hw=cfg["mask_hw"], seed=cfg["xseed"])
+    taps = {}
+
+    def hook(tag):
+        def fn(mod, inp, out):
+            if isinstance(out, tuple):
+                for i, o in enumerate(out):
+                    taps[f"{tag}.{i}"] = o.detach()
+            else:
+                taps[tag] = out.detach()
+        return fn
+
+    for tag in cfg["taps"]:
+        model.get_submodule(tag).register_forward_hook(hook(tag))
+    with torch.no_grad():
+        out, alphas, logits = model(x, z, masks=m)
+    store = {"out": out.numpy()}
+    store["pre_clamp"] = (taps.pop("head") + x).numpy()
+    taps32 = dict(taps)
+    taps.clear()
+    for i, a in enumerate(alphas):
+        store[f"alpha{i}"] = compress(a)
+    if logits is not None:
+        store["logits"] = logits.numpy()
+    for k, v in taps32.items():
+        store["tap:" + k] = compress(v)
+    # fp64 run of the same reference modules: pins the oracle's MATH to ~1e-12,
+    # independent of fp32 summation order.
+    model64 = model.double()
+    with torch.no_grad():
+        o64, a64, l64 = model64(x.double(), z.double(), masks=None if m is None else m.double())
+    store["out_f64"] = o64.numpy()
+    store["pre_clamp_f64"] = (taps.pop("head") + x.double()).numpy()
+    store["alpha_last_f64"] = compress(a64[-1]).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, f"student_{name}.npz"), **store)
+    print(name, "out range", float(out.min()), float(out.max()),
+          "saturated frac", float(((out == 0) | (out == 1)).float().mean()))
+
+
+def dwt_case() -> None:
+    from underwater_ir.student.naf_unet_wfi.dwt_fft import dwt2, idwt2
+    g = torch.Generator().manual_seed(7)
+    store = {}
+    for tag, shape in (("even", (2, 5, 8, 12)), ("odd", (1, 3, 5, 6))):
+        x = torch.randn(shape, generator=g)
+        bands = dwt2(x)
+        store[f"{tag}_x"] = x.numpy()
+        for nm, b in zip(("ll", "lh", "hl", "hh"), bands):
+            store[f"{tag}_{nm}"] = b.numpy()
+        store[f"{tag}_rec"] = idwt2(*bands).numpy()
+    np.savez_compressed(os.path.join(HERE, "dwt.npz"), **store)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    dwt_case()
+    for name, cfg in STUDENT_CASES.items():
+        student_case(name, cfg)
