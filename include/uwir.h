@@ -1,0 +1,174 @@
+/*
+ * uwir.h -- C ABI of libuwir_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * restoration forward pass of anbinh93/Underwater-image-restoration.
+ *
+ * The reference has NO native / FFI layer (pure Python over torch ops), so
+ * each entry point names the reference *Python* function whose device work it replaces
+ * (paths relative to /root/reference).  S/ = underwater_ir/student/naf_unet_wfi/,
+ * L/ = legacy/third_party/universal-image-restoration/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator);
+ *     the library allocates nothing and keeps no mutable global state except the
+ *     thread-local last-error string;
+ *   - activations are NHWC ("token major"): pixel (b,y,x) is row m = (b*H + y)*W + x of a
+ *     row-major [M, ld] matrix, ld >= channels (lets callers write into concat buffers);
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t) and never synchronises;
+ *   - return value: 0 = OK, negative = uwir_status; uwir_last_error() gives the message.
+ */
+#ifndef UWIR_H
+#define UWIR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uwir_stream_t; /* hipStream_t */
+
+enum uwir_status { UWIR_OK = 0, UWIR_EINVAL = -1, UWIR_EUNSUPPORTED = -2, UWIR_ELAUNCH = -3 };
+enum uwir_dtype { UWIR_F32 = 0, UWIR_BF16 = 1 };
+enum uwir_act { UWIR_ACT_NONE = 0, UWIR_ACT_RELU = 1, UWIR_ACT_GELU = 2, UWIR_ACT_SIGMOID = 3, UWIR_ACT_SILU = 4 };
+
+int uwir_version(void);
+const char* uwir_last_error(void);
+
+/* ---- S/dwt_fft.py:33-39 dwt2 -------------------------------------------------------------
+ * x [B,H,W,C] fp32 (pixel stride ldx) -> ll [B,H/2,W/2,C] (stride ld_ll) and
+ * hf [B,H/2,W/2,3C] = [lh|hl|hh] (stride ld_hf); odd trailing row/column dropped like the
+ * reference's stride-2 valid conv.  C % 4 == 0. */
+int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, float* ll, int ld_ll, float* hf, int ld_hf,
+              uwir_stream_t stream);
+
+/* ---- S/dwt_fft.py:42-58 idwt2 ------------------------------------------------------------
+ * ll [B,h,w,C], hf [B,h,w,3C]=[lh|hl|hh] -> out [B,2h,2w,C]. */
+int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf, int B, int h, int w, int C, float* out,
+               int ldo, uwir_stream_t stream);
+
+/* ---- S/utils.py:10-36 LayerNorm2d / AdaLayerNorm2d ------------------------------------------
+ * Per-(b,c) statistics over the n = H*W rows of x [B,n,C]; emits the folded affine
+ *   LN(x)*(1+scale)+shift == a[b,c]*x + s[b,c]
+ * (a = rstd*gamma*(1+scale), s = (beta - mean*rstd*gamma)*(1+scale) + shift) that the
+ * consumer kernel applies while loading x, optionally mean[b,c] (global average pool,
+ * S/deg_head.py:20) and pooled[b,c] = spatial mean of the normalised map (= beta*(1+scale)+shift).  scale_shift [B, ss_ld] holds [scale(C)|shift(C)] per sample or is NULL
+ * (plain LayerNorm2d).  gamma/beta NULL => statistics only (mean_out must be given).
+ * workspace: >= uwir_ln2d_workspace_bytes(B,n,C) bytes.  C % 4 == 0. */
+size_t uwir_ln2d_workspace_bytes(int B, int n, int C);
+int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma, const float* beta,
+                     const float* scale_shift, int ss_ld, float* a_out, float* s_out, float* mean_out,
+                     float* pooled_out, void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+
+/* ---- S/wtb.py:13-28,118-119 ChannelAttention folded into the residual ------------------------
+ * With xn = a*x + s (the affine above) and w = sigmoid(MLP(mean(xn))) [B,C]:
+ *   x + xn*w == x*(1 + a*w) + s*w   ->  out_scale = 1 + a*w, out_shift = s*w   (count = B*C).
+ * mean(xn) needs no reduction: it is pooled_out of uwir_ln2d_affine. */
+int uwir_chan_attn_fold(const float* a, const float* s, const float* w, float* out_scale, float* out_shift, int count,
+                        uwir_stream_t stream);
+
+/* ---- nn.Linear on tiny batches (cond projections S/utils.py:31, S/wfi_gate.py:36; channel
+ * attention MLP S/wtb.py:16-21; degradation head S/deg_head.py:13-17) ------------------------
+ * y[b,o] = act(sum_i x[b,i]*W[o,i] + bias[o]); x stride ldx, y stride ldy. */
+int uwir_linear(const float* x, int ldx, int B, int I, const float* W, const float* bias, int O, int act, float* y,
+                int ldy, uwir_stream_t stream);
+
+/* ---- implicit-GEMM convolution / 1x1 conv / linear on MFMA ----------------------------------
+ * Replaces nn.Conv2d(k=1) (S/wtb.py:50,63,65,71-73; S/sffb.py:32-35; S/cfc.py:19-22;
+ * S/wfi_gate.py:23-25; S/model.py:108), Conv2d(k=2,s=2) / ConvTranspose2d(k=2,s=2)
+ * (S/model.py:93-104), and the k x k convs of the IR-SDE UNet.
+ *   out[m, n] = epilogue( sum_{ky,kx,c} A[b, oy*stride+ky-pad, ox*stride+kx-pad, c] * Wt[n, (ky*KW+kx)*C + c] )
+ * m = (b*OH + oy)*OW + ox.  Out-of-image taps contribute 0 (zero padding is applied AFTER
+ * the optional input affine, like conv(pad)(norm(x))). */
+typedef struct uwir_gemm_args {
+    const void* A;        /* activation, NHWC, a_dtype, pixel stride lda */
+    int a_dtype, lda;
+    int B, H, W, C;       /* input geometry; C % 8 == 0 */
+    int KH, KW, stride, pad;
+    int OH, OW;
+    const float* a_scale; /* optional [B, C] prologue affine (both or neither) */
+    const float* a_shift;
+    const void* Wt;       /* [N, KH*KW*C] row-major, w_dtype == compute dtype */
+    int w_dtype, N;
+    const float* bias;       /* [N] or NULL */
+    const float* batch_bias; /* [B, N] or NULL (per-sample bias, e.g. folded cond_proj of the gate) */
+    int act;                 /* uwir_act, applied to acc + bias + batch_bias */
+    const float* res;        /* optional fp32 residual [M, ldr] added after act */
+    int ldr;
+    const float* res_scale;  /* optional [B, N]: residual enters as res*res_scale + res_shift */
+    const float* res_shift;
+    void* out;               /* [M, ldo] out_dtype (may be NULL when only blend_out is wanted) */
+    int out_dtype, ldo;
+    int store_mode;          /* 0: row m; 1: depth-to-space 2x2 (ConvTranspose2d k=2,s=2): N = 4*Cout,
+                                n = (dy*2+dx)*Cout + co goes to pixel (b, 2*oy+dy, 2*ox+dx), channel co */
+    const float* blend_t;    /* optional gate blend (S/wfi_gate.py:44): blend_out = v*t + (1-v)*f, */
+    const float* blend_f;    /* v = epilogue value, t/f/blend_out fp32 with strides ld_blend_in / ld_blend_out */
+    int ld_blend_in;
+    float* blend_out;
+    int ld_blend_out;
+    int compute;             /* UWIR_F32: exact-fp32 MFMA; UWIR_BF16: bf16 MFMA, fp32 accumulate */
+} uwir_gemm_args;
+int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);
+
+/* ---- multi-scale depthwise conv 3x3 + 5x5 + 7x7 (zero pad) fused with the concat -----------
+ * S/wtb.py:53-62,91 and S/sffb.py:21-31,46 (depthwise halves).  x [B,H,W,C] (x_dtype) ->
+ * out [B,H,W,3C] = [dw3|dw5|dw7] (out_dtype).  Weights are tap-major: w3 [9,C], w5 [25,C],
+ * w7 [49,C]; biases [C] (NULL = 0).  Optional input affine [B,C] (normalise-on-load; padding
+ * stays 0).  C % 4 == 0. */
+int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int C, const float* in_scale,
+                   const float* in_shift, const float* w3, const float* w5, const float* w7, const float* b3,
+                   const float* b5, const float* b7, void* out, int out_dtype, int ldo, uwir_stream_t stream);
+
+/* ---- global multi-head attention, flash style (no n x n matrix) ----------------------------
+ * S/wtb.py:94-115 (one V) and S/cfc.py:24-39 (one softmax(QK^T/sqrt(hd)) applied to two V's).
+ * q,k,v1,v2: [B*n, ld*] matrices (dtype), head h occupies columns [h*hd, (h+1)*hd).
+ * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 64. */
+int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1, const void* v2,
+                    int ldv2, int dtype, int B, int n, int heads, int hd, float scale, void* o1, int ldo1,
+                    void* o2, int ldo2, int out_dtype, uwir_stream_t stream);
+
+/* ---- S/dwt_fft.py:61-72 fft2 / ifft2 (norm="ortho", full complex spectrum) ------------------
+ * fwd: x [B,H,W,C] fp32 -> amp = |F|, phase = atan2(Im,Re) (both [B,H,W,C], stride ld_out).
+ * inv: out = addend + Re(ifft2(amp*exp(i*phase)))  (S/sffb.py:52-54: spatial + freq).
+ * workspace: >= uwir_fft_workspace_bytes(B,H,W,C).  H, W <= 1024; powers of two use an LDS
+ * radix-2 FFT, other lengths a direct DFT. C % 4 == 0. */
+size_t uwir_fft_workspace_bytes(int B, int H, int W, int C);
+int uwir_fft2_amp_phase(const float* x, int ldx, int B, int H, int W, int C, float* amp, float* phase, int ld_out,
+                        void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+int uwir_ifft2_polar_add(const float* amp, const float* phase, int ld_in, const float* addend, int ld_add, int B,
+                         int H, int W, int C, float* out, int ldo, void* workspace, size_t workspace_bytes,
+                         uwir_stream_t stream);
+
+/* ---- F.interpolate(masks, size, mode="bilinear", align_corners=False), S/wfi_gate.py:39-40 --
+ * src NCHW [B,M,hs,ws] fp32 -> dst NHWC rows (pixel stride ldd, M channels written at dst). */
+int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs, int ws, float* dst, int ldd, int hd, int wd,
+                               uwir_stream_t stream);
+
+/* ---- S/model.py:81,133 stem: Conv2d(Cin,Cout,3,padding=1) reading the NCHW input image -------
+ * w repacked [3,3,Cin,Cout]; out NHWC fp32.  Cout % 4 == 0. */
+int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout,
+                      float* out, int ldo, uwir_stream_t stream);
+
+/* ---- S/model.py:158-161 final_norm -> head conv3x3 -> clamp(out + input, 0, 1) ----------------
+ * x NHWC fp32 with the final LayerNorm2d folded as a_scale/a_shift [B,Cin]; w repacked
+ * [Cout,3,3,Cin]; residual/out NCHW fp32; preclamp (optional) receives out+input before the clamp. */
+int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* a_scale,
+                      const float* a_shift, const float* w, const float* bias, int Cout, const float* residual_nchw,
+                      float* out_nchw, float* preclamp_nchw, uwir_stream_t stream);
+
+/* ---- L/utils/sde_utils.py:44-45,177-187,205-231 fused IR-SDE reverse steps --------------------
+ * euler:     x <- x - (theta*(mu-x) - sigma^2*score)*dt - sigma*(eps*sqrt(dt)),  score = -noise/sigma_bar
+ * posterior: x0 = (x - mu - sigma_bar*noise)*expA + mu;  x <- term1*(x-mu) + term2*(x0-mu) + mu + std*eps
+ * All tensors fp32, numel elements, x updated in place (x_out may alias x).  eps may be NULL
+ * (mean step / ODE with half = 0.5). */
+int uwir_sde_euler_step(const float* x, const float* mu, const float* noise, const float* eps, float* x_out,
+                        size_t numel, float theta, float sigma, float sigma_bar, float dt, float score_weight,
+                        uwir_stream_t stream);
+int uwir_sde_posterior_step(const float* x, const float* mu, const float* noise, const float* eps, float* x_out,
+                            size_t numel, float sigma_bar, float expA, float term1, float term2, float std,
+                            uwir_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWIR_H */

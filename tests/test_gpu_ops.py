@@ -1,0 +1,368 @@
+"""GPU parity tests, one per C-ABI entry point: HIP kernel vs the CPU oracle / plain torch fp64 math."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import student_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from underwater_image_restoration_amd import _lib, ops as o
+    _lib.load()  # fail loudly if the HIP library is missing
+    return o
+
+
+def to_rows(t):  # NCHW cpu -> [B*H*W, C] cuda fp32
+    b, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(b * h * w, c).contiguous().float().cuda()
+
+
+def from_rows(t, b, h, w):  # [B*H*W, C] cuda -> NCHW cpu fp64
+    return t.float().reshape(b, h, w, -1).permute(0, 3, 1, 2).double().cpu()
+
+
+def err(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def rel(a, b):
+    return err(a, b) / max(float(b.double().abs().max()), 1e-12)
+
+
+def test_dwt_idwt(ops):
+    g = torch.Generator().manual_seed(1)
+    for (b, c, h, w) in ((2, 8, 8, 12), (1, 4, 5, 6), (1, 64, 32, 32)):
+        x = torch.randn(b, c, h, w, generator=g)
+        ll, lh, hl, hh = R.haar_dwt2(x.double())
+        h2, w2 = h // 2, w // 2
+        dll = torch.empty(b * h2 * w2, c, device="cuda")
+        dhf = torch.empty(b * h2 * w2, 3 * c, device="cuda")
+        ops.dwt2(to_rows(x), b, h, w, c, dll, dhf)
+        assert err(from_rows(dll, b, h2, w2), ll) < 1e-6
+        assert err(from_rows(dhf, b, h2, w2), torch.cat([lh, hl, hh], 1)) < 1e-6
+        out = torch.empty(b * 4 * h2 * w2, c, device="cuda")
+        ops.idwt2(dll, dhf, b, h2, w2, c, out)
+        assert err(from_rows(out, b, 2 * h2, 2 * w2), R.haar_idwt2(ll, lh, hl, hh)) < 1e-6
+    # strided destination (concat buffer): only the addressed columns may change
+    x = torch.randn(1, 4, 4, 4, generator=g)
+    big = torch.full((16, 8), 7.0, device="cuda")
+    ll, lh, hl, hh = R.haar_dwt2(x.double())
+    dll, dhf = to_rows(ll.float()), to_rows(torch.cat([lh, hl, hh], 1).float())
+    ops.idwt2(dll, dhf, 1, 2, 2, 4, big[:, 4:])
+    assert float(big[:, :4].min()) == 7.0 and err(from_rows(big[:, 4:], 1, 4, 4), x.double()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 4, 4), (1, 192, 16, 16), (2, 64, 40, 24), (1, 768, 1, 1)])
+def test_ln2d_affine(ops, shape):
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(shape, generator=g) * 3 + 5
+    sd = {"norm.weight": torch.randn(1, c, 1, 1, generator=g), "norm.bias": torch.randn(1, c, 1, 1, generator=g),
+          "linear.weight": torch.randn(2 * c, 7, generator=g) * 0.2, "linear.bias": torch.randn(2 * c, generator=g)}
+    cond = torch.randn(b, 7, generator=g)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = R.ada_layernorm2d(sd64, "", x.double(), cond.double())
+    ss = F.linear(cond, sd["linear.weight"], sd["linear.bias"]).cuda()
+    xr = to_rows(x)
+    n = h * w
+    a, s, mean, pooled = (torch.empty(b, c, device="cuda") for _ in range(4))
+    ws = torch.empty(max(ops.ln2d_workspace_bytes(b, n, c) // 8, 1), dtype=torch.float64, device="cuda")
+    ops.ln2d_affine(xr, b, n, c, 1e-5, sd["norm.weight"].reshape(-1).cuda(), sd["norm.bias"].reshape(-1).cuda(), ss,
+                    a, s, mean, pooled, ws)
+    got = xr.reshape(b, n, c) * a[:, None, :] + s[:, None, :]
+    tol = 2e-4 if n == 1 else 2e-5
+    assert rel(from_rows(got.reshape(-1, c), b, h, w), ref) < tol
+    assert err(mean.cpu(), x.double().mean(dim=(2, 3))) < 1e-5
+    assert err(pooled.cpu(), ref.mean(dim=(2, 3))) < 1e-4
+    # plain LayerNorm2d (no cond), statistics-only mode
+    a2, s2 = torch.empty(b, c, device="cuda"), torch.empty(b, c, device="cuda")
+    ops.ln2d_affine(xr, b, n, c, 1e-5, sd["norm.weight"].reshape(-1).cuda(), sd["norm.bias"].reshape(-1).cuda(), None,
+                    a2, s2, None, None, ws)
+    got = xr.reshape(b, n, c) * a2[:, None, :] + s2[:, None, :]
+    assert rel(from_rows(got.reshape(-1, c), b, h, w), R.layernorm2d(sd64, "norm.", x.double())) < tol
+    m2 = torch.empty(b, c, device="cuda")
+    ops.ln2d_affine(xr, b, n, c, 1e-5, None, None, None, None, None, m2, None, ws)
+    assert err(m2.cpu(), x.double().mean(dim=(2, 3))) < 1e-5
+
+
+def test_linear_and_fold(ops):
+    g = torch.Generator().manual_seed(3)
+    x, w, bias = torch.randn(3, 513, generator=g), torch.randn(37, 513, generator=g) * 0.05, torch.randn(37, generator=g)
+    for act, fn in ((ops.ACT_NONE, lambda t: t), (ops.ACT_RELU, F.relu), (ops.ACT_GELU, F.gelu),
+                    (ops.ACT_SIGMOID, torch.sigmoid), (ops.ACT_SILU, F.silu)):
+        y = torch.empty(3, 37, device="cuda")
+        ops.linear(x.cuda(), w.cuda(), bias.cuda(), y, act)
+        assert err(y, fn(F.linear(x.double(), w.double(), bias.double()))) < 2e-5
+    a, s, cw = (torch.randn(2, 12, generator=g).cuda() for _ in range(3))
+    os_, oh = torch.empty_like(a), torch.empty_like(a)
+    ops.chan_attn_fold(a, s, cw, os_, oh)
+    assert err(os_, 1 + a * cw) < 1e-6 and err(oh, s * cw) < 1e-6
+
+
+def _wdt(prec):
+    return torch.bfloat16 if prec == "bf16" else torch.float32
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 48, 144), (1, 16, 16, 192, 576), (3, 9, 11, 64, 64), (1, 2, 2, 1728, 200)])
+def test_conv_gemm_1x1_epilogues(ops, prec, shape):
+    b, h, w, k, n = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b, k, h, w, generator=g)
+    wt = torch.randn(n, k, generator=g) / math.sqrt(k)
+    bias, bb = torch.randn(n, generator=g), torch.randn(b, n, generator=g)
+    asc, ash = torch.rand(b, k, generator=g) + 0.5, torch.randn(b, k, generator=g)
+    res = torch.randn(b, n, h, w, generator=g)
+    rsc, rsh = torch.rand(b, n, generator=g) + 0.5, torch.randn(b, n, generator=g)
+    tol = 2e-5 if prec == "fp32" else 3e-2
+    wd = wt.to(_wdt(prec)).cuda()
+    xr = to_rows(x)
+    # (1) affine prologue + bias + per-sample bias + GELU
+    xa = x.double() * asc[:, :, None, None].double() + ash[:, :, None, None].double()
+    ref = F.gelu(F.conv2d(xa, wt.double()[:, :, None, None], bias.double()) + bb.double()[:, :, None, None])
+    out = torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(xr, wd, out, B=b, H=h, W=w, C_=k, N=n, a_scale=asc.cuda(), a_shift=ash.cuda(), bias=bias.cuda(),
+                  batch_bias=bb.cuda(), act=ops.ACT_GELU)
+    assert rel(from_rows(out, b, h, w), ref) < tol
+    # (2) affine residual, bf16 / strided output
+    ref2 = F.conv2d(x.double(), wt.double()[:, :, None, None], bias.double()) + res.double() * rsc.double()[:, :, None, None] \
+        + rsh.double()[:, :, None, None]
+    big = torch.zeros(b * h * w, n + 8, device="cuda", dtype=_wdt(prec))
+    ops.conv_gemm(xr, wd, big[:, 8:], B=b, H=h, W=w, C_=k, N=n, bias=bias.cuda(), res=to_rows(res), res_scale=rsc.cuda(),
+                  res_shift=rsh.cuda())
+    assert rel(from_rows(big[:, 8:], b, h, w), ref2) < (tol if prec == "fp32" else 4e-2)
+    assert float(big[:, :8].float().abs().max()) == 0.0
+    # (3) sigmoid + gate blend
+    t, f = torch.randn(b, n, h, w, generator=g), torch.randn(b, n, h, w, generator=g)
+    al = torch.sigmoid(F.conv2d(x.double(), wt.double()[:, :, None, None], bias.double()))
+    tf = torch.cat([to_rows(t), to_rows(f)], dim=1)
+    alpha, merged = torch.empty(b * h * w, n, device="cuda"), torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(xr, wd, alpha, B=b, H=h, W=w, C_=k, N=n, bias=bias.cuda(), act=ops.ACT_SIGMOID, blend_t=tf[:, :n],
+                  blend_f=tf[:, n:], blend_out=merged)
+    assert err(from_rows(alpha, b, h, w), al) < (1e-5 if prec == "fp32" else 2e-2)
+    assert rel(from_rows(merged, b, h, w), al * t.double() + (1 - al) * f.double()) < (1e-5 if prec == "fp32" else 2e-2)
+    if prec == "bf16":  # bf16 activations as the A operand
+        out2 = torch.empty(b * h * w, n, device="cuda")
+        ops.conv_gemm(xr.to(torch.bfloat16), wd, out2, B=b, H=h, W=w, C_=k, N=n, bias=bias.cuda())
+        assert rel(from_rows(out2, b, h, w), F.conv2d(x.double(), wt.double()[:, :, None, None], bias.double())) < tol
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_gemm_spatial(ops, prec):
+    g = torch.Generator().manual_seed(5)
+    tol = 2e-5 if prec == "fp32" else 3e-2
+    b, c, h, w, n = 2, 64, 12, 8, 128
+    x = torch.randn(b, c, h, w, generator=g)
+    xr = to_rows(x)
+    # Conv2d(k=2, s=2)  (S/model.py:93-96)
+    wt = torch.randn(n, c, 2, 2, generator=g) / math.sqrt(4 * c)
+    bias = torch.randn(n, generator=g)
+    out = torch.empty(b * (h // 2) * (w // 2), n, device="cuda")
+    ops.conv_gemm(xr, wt.permute(0, 2, 3, 1).reshape(n, -1).to(_wdt(prec)).cuda().contiguous(), out, B=b, H=h, W=w, C_=c,
+                  N=n, KH=2, KW=2, stride=2, pad=0, bias=bias.cuda())
+    assert rel(from_rows(out, b, h // 2, w // 2), F.conv2d(x.double(), wt.double(), bias.double(), stride=2)) < tol
+    # Conv2d(k=3, p=1) with normalise-on-load: padding must stay zero AFTER the affine
+    wt3 = torch.randn(n, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    asc, ash = torch.rand(b, c, generator=g) + 0.5, torch.randn(b, c, generator=g)
+    xa = x.double() * asc.double()[:, :, None, None] + ash.double()[:, :, None, None]
+    out3 = torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(xr, wt3.permute(0, 2, 3, 1).reshape(n, -1).to(_wdt(prec)).cuda().contiguous(), out3, B=b, H=h, W=w,
+                  C_=c, N=n, KH=3, KW=3, stride=1, pad=1, a_scale=asc.cuda(), a_shift=ash.cuda(), act=ops.ACT_SILU)
+    assert rel(from_rows(out3, b, h, w), F.silu(F.conv2d(xa, wt3.double(), padding=1))) < tol
+    # Conv2d(k=4, s=2, p=1)  (IR-SDE UNet downsample)
+    wt4 = torch.randn(n, c, 4, 4, generator=g) / math.sqrt(16 * c)
+    out4 = torch.empty(b * (h // 2) * (w // 2), n, device="cuda")
+    ops.conv_gemm(xr, wt4.permute(0, 2, 3, 1).reshape(n, -1).to(_wdt(prec)).cuda().contiguous(), out4, B=b, H=h, W=w,
+                  C_=c, N=n, KH=4, KW=4, stride=2, pad=1)
+    assert rel(from_rows(out4, b, h // 2, w // 2), F.conv2d(x.double(), wt4.double(), stride=2, padding=1)) < tol
+    # ConvTranspose2d(k=2, s=2) as GEMM + depth-to-space into the left half of a concat buffer (S/model.py:98-104)
+    co = 32
+    wtt = torch.randn(c, co, 2, 2, generator=g) / math.sqrt(c)
+    bt = torch.randn(co, generator=g)
+    cat = torch.full((b * 4 * h * w, 2 * co), 3.0, device="cuda")
+    ops.conv_gemm(xr, wtt.permute(2, 3, 1, 0).reshape(4 * co, c).to(_wdt(prec)).cuda().contiguous(), cat[:, :co], B=b, H=h,
+                  W=w, C_=c, N=4 * co, bias=bt.repeat(4).cuda(), store_mode=1)
+    assert rel(from_rows(cat[:, :co], b, 2 * h, 2 * w), F.conv_transpose2d(x.double(), wtt.double(), bt.double(), stride=2)) < tol
+    assert float(cat[:, co:].min()) == 3.0
+
+
+def test_conv_gemm_rejects_bad_arguments(ops):
+    x = torch.zeros(16, 12, device="cuda")
+    w = torch.zeros(8, 12, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, w.to(torch.bfloat16), torch.empty(16, 8, device="cuda"), B=1, H=4, W=4, C_=12, N=8)  # C % 8
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, w, torch.empty(16, 4, device="cuda"), B=1, H=4, W=4, C_=12, N=8)  # ldo < N
+
+
+@pytest.mark.parametrize("io", [("fp32", "fp32"), ("fp32", "bf16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("shape", [(2, 48, 9, 21), (1, 576, 16, 16), (1, 20, 3, 2), (2, 64, 40, 8)])
+def test_dwconv_ms(ops, io, shape):
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(shape, generator=g)
+    ws = [torch.randn(c, 1, k, k, generator=g) / k for k in (3, 5, 7)]
+    bs = [torch.randn(c, generator=g) for _ in range(3)]
+    asc, ash = torch.rand(b, c, generator=g) + 0.5, torch.randn(b, c, generator=g)
+    idt, odt = (torch.bfloat16 if t == "bf16" else torch.float32 for t in io)
+    xin = to_rows(x).to(idt)
+    xe = xin.float().cpu().reshape(b, h, w, c).permute(0, 3, 1, 2).double()
+    taps = tuple(wk.reshape(c, -1).t().contiguous().cuda() for wk in ws)
+    for use_aff in (False, True):
+        xa = xe * asc.double()[:, :, None, None] + ash.double()[:, :, None, None] if use_aff else xe
+        ref = torch.cat([F.conv2d(xa, wk.double(), bk.double(), padding=wk.shape[-1] // 2, groups=c) for wk, bk in zip(ws, bs)], 1)
+        out = torch.empty(b * h * w, 3 * c, device="cuda", dtype=odt)
+        ops.dwconv_ms(xin, b, h, w, c, taps, tuple(t.cuda() for t in bs), out,
+                      in_scale=asc.cuda() if use_aff else None, in_shift=ash.cuda() if use_aff else None)
+        assert rel(from_rows(out, b, h, w), ref) < (1e-5 if odt == torch.float32 else 1e-2)
+
+
+def _attn_ref(q, k, vs, heads, hd):
+    b, n, _ = q.shape
+    qh = q.reshape(b, n, heads, hd).permute(0, 2, 1, 3)
+    kh = k.reshape(b, n, heads, hd).permute(0, 2, 1, 3)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+    return [(a @ v.reshape(b, n, heads, hd).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(b, n, heads * hd) for v in vs]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 16, 12, 16, 1), (1, 50, 12, 16, 1), (1, 1000, 3, 32, 1), (2, 200, 2, 64, 1),
+                                 (1, 1, 4, 16, 2), (2, 333, 4, 16, 2), (1, 129, 4, 32, 2), (1, 257, 4, 64, 2),
+                                 (1, 70, 12, 4, 1), (1, 70, 4, 8, 2), (1, 4096, 2, 16, 1)])
+def test_flash_attn(ops, prec, cfg):
+    b, n, heads, hd, nv = cfg
+    g = torch.Generator().manual_seed(7)
+    wdt = heads * hd
+    dt = _wdt(prec)
+    # one wide buffer holding q|k|v (strided views, like the fused qkv GEMM output)
+    qkv = (torch.randn(b * n, 3 * wdt + 8, generator=g) * 1.5).to(dt)
+    v2 = torch.randn(b * n, wdt, generator=g).to(dt)
+    q, k, v = qkv[:, :wdt], qkv[:, wdt:2 * wdt], qkv[:, 2 * wdt:3 * wdt]
+    vs = [v] + ([v2] if nv == 2 else [])
+    refs = _attn_ref(q.double().reshape(b, n, wdt), k.double().reshape(b, n, wdt), [t.double().reshape(b, n, wdt) for t in vs],
+                     heads, hd)
+    dq = qkv.cuda()
+    dv2 = v2.cuda() if nv == 2 else None
+    o = torch.full((b * n, 2 * wdt + 4), -9.0, device="cuda")  # fp32 outputs side by side (gate-input layout)
+    ops.flash_attn(dq[:, :wdt], dq[:, wdt:2 * wdt], dq[:, 2 * wdt:3 * wdt], dv2, b, n, heads, hd, 1.0 / math.sqrt(hd),
+                   o[:, :wdt], o[:, wdt:2 * wdt] if nv == 2 else None)
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    assert err(o[:, :wdt].reshape(b, n, wdt), refs[0]) < tol
+    if nv == 2:
+        assert err(o[:, wdt:2 * wdt].reshape(b, n, wdt), refs[1]) < tol
+    else:
+        assert float(o[:, wdt:].max()) == -9.0
+    assert float(o[:, 2 * wdt:].max()) == -9.0
+    if prec == "bf16":  # bf16 output buffer
+        ob = torch.empty(b * n, wdt, device="cuda", dtype=torch.bfloat16)
+        ops.flash_attn(dq[:, :wdt], dq[:, wdt:2 * wdt], dq[:, 2 * wdt:3 * wdt], None, b, n, heads, hd, 1.0 / math.sqrt(hd), ob, None)
+        assert err(ob.reshape(b, n, wdt), refs[0]) < 4e-2
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_flash_attn_forced_rescale(ops, prec):
+    """A key whose score jumps far above the running max late in the sequence forces the deferred-max rescale."""
+    b, n, heads, hd = 1, 300, 1, 16
+    g = torch.Generator().manual_seed(8)
+    q, k, v = (torch.randn(n, hd, generator=g) for _ in range(3))
+    k[250] = q[5] * 6.0   # spike for query 5 in the 4th key tile
+    k[299] = q[100] * 9.0
+    dt = _wdt(prec)
+    q, k, v = q.to(dt), k.to(dt), v.to(dt)
+    (ref,) = _attn_ref(q.double()[None], k.double()[None], [v.double()[None]], heads, hd)
+    o = torch.empty(n, hd, device="cuda")
+    ops.flash_attn(q.cuda(), k.cuda(), v.cuda(), None, b, n, heads, hd, 1.0 / math.sqrt(hd), o, None)
+    assert err(o[None], ref) < (2e-5 if prec == "fp32" else 2e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 128, 128), (2, 20, 8, 32), (1, 4, 1, 1), (1, 8, 12, 10), (1, 4, 2, 4)])
+def test_fft_roundtrip_and_parts(ops, shape):
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(shape, generator=g) - 0.3
+    spec = torch.fft.fft2(x.double(), norm="ortho")
+    im = spec.imag.clone()
+    for ky in ({0, h // 2} if h % 2 == 0 else {0}):
+        for kx in ({0, w // 2} if w % 2 == 0 else {0}):
+            im[..., ky, kx] = 0.0
+    xr = to_rows(x)
+    amp, ph = torch.empty_like(xr), torch.empty_like(xr)
+    ws = torch.empty(ops.fft_workspace_bytes(b, h, w, c) // 4, device="cuda")
+    ops.fft2_amp_phase(xr, b, h, w, c, amp, ph, ws)
+    ref_amp, ref_ph = torch.complex(spec.real, im).abs(), torch.atan2(im, spec.real)
+    assert err(from_rows(amp, b, h, w), ref_amp) < 2e-5 * max(1.0, float(ref_amp.max()))
+    # phase is discontinuous at +-pi: compare on the circle, weighted by the amplitude
+    dphi = from_rows(ph, b, h, w) - ref_ph
+    assert float((torch.abs(torch.sin(dphi / 2)) * ref_amp).max()) < 2e-5 * max(1.0, float(ref_amp.max()))
+    got_ph = from_rows(ph, b, h, w)
+    for ky in ({0, h // 2} if h % 2 == 0 else {0}):  # self-conjugate bins: exactly 0 or +pi, never -pi
+        for kx in ({0, w // 2} if w % 2 == 0 else {0}):
+            assert torch.equal(got_ph[..., ky, kx].float(), ref_ph[..., ky, kx].float())
+    # inverse with a modulated spectrum + addend
+    amp2 = torch.randn(shape, generator=g)
+    ph2 = torch.randn(shape, generator=g) * 4
+    add = torch.randn(shape, generator=g)
+    ref = add.double() + torch.fft.ifft2(torch.complex(amp2.double() * torch.cos(ph2.double()), amp2.double() * torch.sin(ph2.double())),
+                                         norm="ortho").real
+    out = torch.empty_like(xr)
+    ops.ifft2_polar_add(to_rows(amp2), to_rows(ph2), to_rows(add), b, h, w, c, out, ws)
+    assert err(from_rows(out, b, h, w), ref) < 2e-5
+
+
+def test_bilinear(ops):
+    g = torch.Generator().manual_seed(10)
+    for (hs, ws_, hd, wd) in ((7, 7, 16, 16), (224, 224, 16, 8), (224, 224, 4, 4), (8, 8, 8, 8), (7, 7, 1, 1)):
+        src = torch.rand(2, 10, hs, ws_, generator=g)
+        ref = F.interpolate(src, size=(hd, wd), mode="bilinear", align_corners=False)
+        dst = torch.full((2 * hd * wd, 16), 5.0, device="cuda")
+        ops.bilinear_nchw_to_nhwc(src.cuda(), dst[:, 4:14], hd, wd)
+        assert err(from_rows(dst[:, 4:14], 2, hd, wd), ref) < 1e-6
+        assert float(dst[:, :4].min()) == 5.0 and float(dst[:, 14:].min()) == 5.0
+
+
+def test_stem_and_head(ops):
+    g = torch.Generator().manual_seed(11)
+    b, h, w = 2, 12, 20
+    x = torch.rand(b, 3, h, w, generator=g)
+    ws_, bs_ = torch.randn(64, 3, 3, 3, generator=g) * 0.2, torch.randn(64, generator=g)
+    out = torch.empty(b * h * w, 64, device="cuda")
+    ops.stem_conv3x3(x.cuda(), ws_.permute(2, 3, 1, 0).contiguous().cuda(), bs_.cuda(), out)
+    assert err(from_rows(out, b, h, w), F.conv2d(x.double(), ws_.double(), bs_.double(), padding=1)) < 1e-5
+    feat = torch.randn(b, 64, h, w, generator=g)
+    wh, bh = torch.randn(3, 64, 3, 3, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1
+    asc, ash = torch.rand(b, 64, generator=g) + 0.5, torch.randn(b, 64, generator=g)
+    fa = feat.double() * asc.double()[:, :, None, None] + ash.double()[:, :, None, None]
+    pre_ref = F.conv2d(fa, wh.double(), bh.double(), padding=1) + x.double()
+    o, pre = torch.empty(b, 3, h, w, device="cuda"), torch.empty(b, 3, h, w, device="cuda")
+    ops.head_conv3x3(to_rows(feat), b, h, w, 64, asc.cuda(), ash.cuda(), wh.permute(0, 2, 3, 1).contiguous().cuda(), bh.cuda(), 3,
+                     x.cuda(), o, pre)
+    assert err(pre, pre_ref) < 2e-5 and err(o, pre_ref.clamp(0, 1)) < 2e-5
+
+
+def test_sde_steps(ops):
+    g = torch.Generator().manual_seed(12)
+    for numel in (3 * 64 * 64 * 2, 1027):
+        x, mu, nz, eps = (torch.randn(numel, generator=g) for _ in range(4))
+        theta, sigma, sbar, dt = 0.013, 0.0316, 0.19, 0.104
+        score = -nz.double() / sbar
+        ref = x.double() - (theta * (mu.double() - x.double()) - sigma ** 2 * score) * dt - sigma * (eps.double() * math.sqrt(dt))
+        xo = torch.empty(numel, device="cuda")
+        ops.sde_euler_step(x.cuda(), mu.cuda(), nz.cuda(), eps.cuda(), xo, theta, sigma, sbar, dt)
+        assert err(xo, ref) < 1e-5
+        ref_ode = x.double() - (theta * (mu.double() - x.double()) - 0.5 * sigma ** 2 * score) * dt
+        ops.sde_euler_step(x.cuda(), mu.cuda(), nz.cuda(), None, xo, theta, sigma, sbar, dt, 0.5)
+        assert err(xo, ref_ode) < 1e-5
+        expA, t1, t2, sd = 1.7, 0.8, 0.15, 0.02
+        x0 = (x.double() - mu.double() - sbar * nz.double()) * expA + mu.double()
+        refp = t1 * (x.double() - mu.double()) + t2 * (x0 - mu.double()) + mu.double() + sd * eps.double()
+        xc = x.cuda()
+        ops.sde_posterior_step(xc, mu.cuda(), nz.cuda(), eps.cuda(), xc, sbar, expA, t1, t2, sd)  # in place
+        assert err(xc, refp) < 1e-5

@@ -1,0 +1,93 @@
+"""ctypes binding of libuwir_hip.so (the C ABI declared in include/uwir.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuwir_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3, 4
+
+vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    """Mirror of ``struct uwir_gemm_args`` (include/uwir.h) -- field order is ABI."""
+    _fields_ = [
+        ("A", vp), ("a_dtype", ci), ("lda", ci),
+        ("B", ci), ("H", ci), ("W", ci), ("C", ci),
+        ("KH", ci), ("KW", ci), ("stride", ci), ("pad", ci),
+        ("OH", ci), ("OW", ci),
+        ("a_scale", vp), ("a_shift", vp),
+        ("Wt", vp), ("w_dtype", ci), ("N", ci),
+        ("bias", vp), ("batch_bias", vp), ("act", ci),
+        ("res", vp), ("ldr", ci),
+        ("res_scale", vp), ("res_shift", vp),
+        ("out", vp), ("out_dtype", ci), ("ldo", ci),
+        ("store_mode", ci),
+        ("blend_t", vp), ("blend_f", vp), ("ld_blend_in", ci),
+        ("blend_out", vp), ("ld_blend_out", ci),
+        ("compute", ci),
+    ]
+
+
+_SIGS = {
+    "uwir_version": (ci, []),
+    "uwir_last_error": (C.c_char_p, []),
+    "uwir_dwt2": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
+    "uwir_idwt2": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "uwir_ln2d_workspace_bytes": (sz, [ci, ci, ci]),
+    "uwir_ln2d_affine": (ci, [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
+    "uwir_chan_attn_fold": (ci, [vp, vp, vp, vp, vp, ci, vp]),
+    "uwir_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]),
+    "uwir_conv_gemm": (ci, [C.POINTER(GemmArgs), vp]),
+    "uwir_dwconv_ms": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "uwir_flash_attn": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, vp, ci, vp, ci, ci, vp]),
+    "uwir_fft_workspace_bytes": (sz, [ci, ci, ci, ci]),
+    "uwir_fft2_amp_phase": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, sz, vp]),
+    "uwir_ifft2_polar_add": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, sz, vp]),
+    "uwir_bilinear_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
+    "uwir_stem_conv3x3": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, ci, vp]),
+    "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
+    "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+class UwirError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UwirError(f"{LIB_PATH} is missing: build it with `python -m underwater_image_restoration_amd.build` "
+                        "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().uwir_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise UwirError(f"{what}: rc={rc}: {msg}")

@@ -1,0 +1,309 @@
+// Global multi-head attention, flash style (online softmax, no n x n matrix in memory).
+//   S/wtb.py:94-115  (one V)   and   S/cfc.py:24-39 (one softmax(QK^T/sqrt(hd)), two V's)
+//
+// Block = 4 waves x 32 queries; keys/values stream through LDS in 64-key tiles (register
+// prefetch of the next tile overlaps the MFMAs of the current one).  Per wave and 32-key block:
+//   S^T[key][query] = K . Q^T          -- "swapped" QK^T: the query sits on the lane, so the row
+//                                         max / sum are register reductions + ONE half exchange
+//   P = exp2(c*S - m)                  -- deferred-max online softmax (rescale only when needed)
+//   O^T[d][query] += V^T[d][key] . P   -- the 32x32 accumulator of S^T IS the B operand of this
+//                                         MFMA (rows = keys = the summed index): no LDS round trip
+// bf16 path: v_mfma_f32_32x32x16_bf16, V^T is staged with the key permutation that the
+// accumulator-as-operand register order implies; fp32 path: v_mfma_f32_32x32x2_f32 (exact f32).
+#include "common.h"
+#include <type_traits>
+
+struct AttnP {
+    const void *q, *k, *v[2];
+    void* o[2];
+    int ldq, ldk, ldv[2], ldo[2];
+    int n, heads, hd, out_dtype;
+    float c;  // scale * log2(e)
+};
+
+#define AT_KT 64
+
+template <typename T> struct Chunk4;
+template <> struct Chunk4<bf16_t> { typedef bf16x4 type; };
+template <> struct Chunk4<float> { typedef f32x4 type; };
+
+template <typename T, int HD, int NV>
+__global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KT = AT_KT;
+    constexpr int KSTR = HD + (BF ? 8 : 1);   // sK row stride (elements)
+    constexpr int VSTR = KT + (BF ? 8 : 1);   // sVt row stride
+    constexpr int DV = HD * NV;
+    constexpr int DG = (DV + 31) / 32;         // 32-row d groups of O^T
+    constexpr int NKC = (KT * (HD / 4)) / 256; // K chunks (4 elements) per thread per tile
+    constexpr int QPR = HD / 4;                // chunks per key row
+    using C4 = typename Chunk4<T>::type;
+
+    __shared__ __attribute__((aligned(16))) T sK[2][KT * KSTR];
+    __shared__ __attribute__((aligned(16))) T sVt[2][DG * 32 * VSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int n = p.n, hd = p.hd;
+    const size_t row0 = (size_t)b * n;
+    const int q_idx = blockIdx.x * 128 + wave * 32 + lq;  // this lane's query
+    const float c = p.c;
+
+    const T* __restrict__ Kp = (const T*)p.k + (size_t)head * hd;
+    const T* __restrict__ Vp0 = (const T*)p.v[0] + (size_t)head * hd;
+    const T* __restrict__ Vp1 = NV > 1 ? (const T*)p.v[1] + (size_t)head * hd : nullptr;
+
+    // ---- zero the V^T image once (rows / columns never written must read as 0, not NaN garbage)
+    for (int i = tid; i < 2 * DG * 32 * VSTR; i += 256) (&sVt[0][0])[i] = (T)0.f;
+    for (int i = tid; i < 2 * KT * KSTR; i += 256) (&sK[0][0])[i] = (T)0.f;
+
+    // ---- Q fragments straight from global
+    constexpr int KS = BF ? HD / 16 : HD / 2;
+    typedef typename std::conditional<BF, bf16x8, float>::type QF;
+    QF qf[KS];
+    {
+        const T* Qp = (const T*)p.q + (size_t)head * hd;
+        const bool qok = q_idx < n;
+        const T* qrow = Qp + (row0 + (qok ? q_idx : 0)) * p.ldq;
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 f;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int d = 16 * ks + 8 * lh + 4 * half;
+                    bf16x4 v;
+                    if (qok && d < hd) v = *reinterpret_cast<const bf16x4*>(qrow + d);
+                    else { v[0] = v[1] = v[2] = v[3] = (bf16_t)0.f; }
+                    f[4 * half] = v[0]; f[4 * half + 1] = v[1]; f[4 * half + 2] = v[2]; f[4 * half + 3] = v[3];
+                }
+                qf[ks] = f;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int d = 2 * ks + lh;
+                qf[ks] = (qok && d < hd) ? (float)qrow[d] : 0.f;
+            }
+        }
+    }
+
+    // ---- staging registers
+    C4 rk[NKC], rv[NV][NKC];
+    auto zero4 = [](C4& v) { v[0] = (T)0.f; v[1] = (T)0.f; v[2] = (T)0.f; v[3] = (T)0.f; };
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            int cidx = tid + 256 * i;
+            int key = k0 + cidx / QPR, d = 4 * (cidx % QPR);
+            bool ok = key < n && d < hd;
+            size_t r = row0 + (ok ? key : 0);
+            if (ok) {
+                rk[i] = *reinterpret_cast<const C4*>(Kp + r * p.ldk + d);
+                rv[0][i] = *reinterpret_cast<const C4*>(Vp0 + r * p.ldv[0] + d);
+                if constexpr (NV > 1) rv[1][i] = *reinterpret_cast<const C4*>(Vp1 + r * p.ldv[1] + d);
+            } else {
+                zero4(rk[i]);
+                zero4(rv[0][i]);
+                if constexpr (NV > 1) zero4(rv[1][i]);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            int cidx = tid + 256 * i;
+            int key = cidx / QPR, d = 4 * (cidx % QPR);
+            if constexpr (BF) {
+                *reinterpret_cast<bf16x4*>(&sK[buf][key * KSTR + d]) = rk[i];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sK[buf][key * KSTR + d + e] = rk[i][e];
+            }
+            int pos = key;
+            if constexpr (BF) {
+                int kk = key & 15;
+                pos = (key & ~15) + 8 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sVt[buf][(v * HD + d + e) * VSTR + pos] = rv[v][i][e];
+        }
+    };
+
+    f32x16 O[DG];
+#pragma unroll
+    for (int g = 0; g < DG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[g][r] = 0.f;
+    float m_run = -1e30f;  // running max in scaled (log2) units
+    float l_run = 0.f;     // this lane's partial denominator (its 16 keys of every 32)
+    constexpr float THR = BF ? 4.f : 0.f;
+
+    const int ntiles = (n + KT - 1) / KT;
+    __syncthreads();
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile((t + 1) * KT);
+        const int k0 = t * KT;
+        const bool tail = k0 + KT > n;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (k0 + kb * 32 >= n) break;  // whole 32-key block out of range (wave-uniform)
+            // ---- S^T = K . Q^T
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            if constexpr (BF) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][(kb * 32 + lq) * KSTR + 16 * ks + 8 * lh]);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    float kf = sK[buf][(kb * 32 + lq) * KSTR + 2 * ks + lh];
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[ks], s, 0, 0, 0);
+                }
+            }
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= n) s[r] = -INFINITY;
+                }
+            }
+            // ---- online softmax (deferred max)
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            {
+                unsigned u = __float_as_uint(mx);
+                auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            float mxs = mx * c;
+            if (__any(mxs > m_run + THR)) {
+                float m_new = fmaxf(m_run, mxs);
+                float alpha = exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int g = 0; g < DG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[g][r] *= alpha;
+            }
+            float pr[16];
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -m_run));
+                lsum += pr[r];
+            }
+            l_run += lsum;
+            // ---- O^T += V^T . P
+            if constexpr (BF) {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    bf16x8 pb;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
+#pragma unroll
+                    for (int g = 0; g < DG; ++g) {
+                        bf16x8 vf = *reinterpret_cast<const bf16x8*>(
+                            &sVt[buf][(g * 32 + lq) * VSTR + kb * 32 + 16 * ss + 8 * lh]);
+                        O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                    for (int g = 0; g < DG; ++g) {
+                        float vf = sVt[buf][(g * 32 + lq) * VSTR + key];
+                        O[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], O[g], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finish: combine the two half-wave denominators, normalise, store
+    {
+        unsigned u = __float_as_uint(l_run);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (q_idx >= n) return;
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int g = 0; g < DG; ++g) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int d = g * 32 + 8 * rq + 4 * lh;  // rows d..d+3 live in regs 4*rq..4*rq+3
+            const int v = d / HD, dd = d % HD;
+            if (v < NV && dd < hd) {
+                float4 o = make_float4(O[g][4 * rq] * inv, O[g][4 * rq + 1] * inv, O[g][4 * rq + 2] * inv,
+                                       O[g][4 * rq + 3] * inv);
+                size_t off = (row0 + q_idx) * p.ldo[v] + (size_t)head * hd + dd;
+                if (p.out_dtype == UWIR_F32) store4((float*)p.o[v] + off, o);
+                else store4((bf16_t*)p.o[v] + off, o);
+            }
+        }
+    }
+}
+
+template <typename T, int HD>
+static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
+    dim3 grid(ceil_div(p.n, 128), p.heads, B);
+    if (nv == 1) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2>), grid, dim3(256), 0, stream, p);
+    UWIR_LAUNCH_CHECK("flash_attn");
+    return UWIR_OK;
+}
+
+template <typename T>
+static int launch_attn(const AttnP& p, int nv, int B, hipStream_t stream) {
+    if (p.hd <= 16) return launch_attn_nv<T, 16>(p, nv, B, stream);
+    if (p.hd <= 32) return launch_attn_nv<T, 32>(p, nv, B, stream);
+    return launch_attn_nv<T, 64>(p, nv, B, stream);
+}
+
+extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1,
+                               const void* v2, int ldv2, int dtype, int B, int n, int heads, int hd, float scale,
+                               void* o1, int ldo1, void* o2, int ldo2, int out_dtype, uwir_stream_t stream) {
+    UWIR_CHECK(q && k && v1 && o1, "flash_attn: null pointer");
+    UWIR_CHECK((v2 == nullptr) == (o2 == nullptr), "flash_attn: v2 and o2 must come together");
+    UWIR_CHECK(B > 0 && B <= 65535 && heads > 0 && heads <= 65535 && n > 0, "flash_attn: bad shape");
+    UWIR_CHECK(hd > 0 && hd <= 64 && hd % 4 == 0, "flash_attn: head_dim must be a multiple of 4, <= 64 (got %d)", hd);
+    UWIR_CHECK(dtype == UWIR_F32 || dtype == UWIR_BF16, "flash_attn: bad dtype");
+    UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "flash_attn: bad out dtype");
+    int w = heads * hd;
+    UWIR_CHECK(ldq >= w && ldk >= w && ldv1 >= w && ldo1 >= w && (!v2 || (ldv2 >= w && ldo2 >= w)),
+               "flash_attn: leading dimension smaller than heads*hd");
+    UWIR_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv1 % 4 == 0 && ldo1 % 4 == 0 && ldv2 % 4 == 0 && ldo2 % 4 == 0,
+               "flash_attn: leading dimensions must be multiples of 4");
+    const uintptr_t am = dtype == UWIR_BF16 ? 7 : 15;
+    UWIR_CHECK(((uintptr_t)q & am) == 0 && ((uintptr_t)k & am) == 0 && ((uintptr_t)v1 & am) == 0 &&
+                   ((uintptr_t)v2 & am) == 0,
+               "flash_attn: misaligned input pointer");
+    AttnP p;
+    p.q = q; p.k = k; p.v[0] = v1; p.v[1] = v2;
+    p.o[0] = o1; p.o[1] = o2;
+    p.ldq = ldq; p.ldk = ldk; p.ldv[0] = ldv1; p.ldv[1] = ldv2; p.ldo[0] = ldo1; p.ldo[1] = ldo2;
+    p.n = n; p.heads = heads; p.hd = hd; p.out_dtype = out_dtype;
+    p.c = scale * 1.4426950408889634f;
+    int nv = v2 ? 2 : 1;
+    if (dtype == UWIR_BF16) return launch_attn<bf16_t>(p, nv, B, (hipStream_t)stream);
+    return launch_attn<float>(p, nv, B, (hipStream_t)stream);
+}

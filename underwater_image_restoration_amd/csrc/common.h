@@ -1,0 +1,56 @@
+// Shared device/host helpers for libuwir_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/uwir.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UWIR_WAVE 64
+
+int uwir_set_error(int code, const char* fmt, ...);
+
+#define UWIR_CHECK(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return uwir_set_error(UWIR_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define UWIR_LAUNCH_CHECK(name)                                                          \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) return uwir_set_error(UWIR_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case UWIR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case UWIR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact (erf) GELU
+        case UWIR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case UWIR_ACT_SILU: return v / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+
+// 4 consecutive elements -> float4, for either storage type
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+}

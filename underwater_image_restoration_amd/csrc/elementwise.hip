@@ -1,0 +1,562 @@
+// HBM-bound kernels: Haar DWT/IDWT, LayerNorm2d statistics -> folded affine, tiny linears,
+// bilinear mask resize, stem/head 3x3 convs, fused IR-SDE steps.  All NHWC, fp32, float4 lanes.
+#include "common.h"
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int uwir_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* uwir_last_error(void) { return g_err; }
+extern "C" int uwir_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------------
+// Haar DWT / IDWT.  The reference tap is fl32(2^-0.5)^2 (S/dwt_fft.py:10-21), not 0.5.
+// One thread = one output pixel x 4 channels: reads 4 float4, writes 4 float4.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float haar_tap() {
+    const float s = 0.70710678118654752440f;
+    return s * s;
+}
+
+__global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, int ldx, int H, int W, int C4, int h,
+                                                   int w, float* __restrict__ ll, int ld_ll, float* __restrict__ hf,
+                                                   int ld_hf, size_t total) {
+    const float k = haar_tap();
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t p = i / C4;  // output pixel (b, y, x)
+        int ox = (int)(p % w);
+        size_t q = p / w;
+        int oy = (int)(q % h);
+        int b = (int)(q / h);
+        const float* r0 = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * ldx + 4 * c4;
+        const float* r1 = r0 + (size_t)W * ldx;
+        float4 a = load4(r0), bb = load4(r0 + ldx), c = load4(r1), d = load4(r1 + ldx);
+        float4 o_ll, o_lh, o_hl, o_hh;
+#define HAAR(F)                                             \
+    o_ll.F = k * a.F + k * bb.F + k * c.F + k * d.F;        \
+    o_lh.F = k * a.F - k * bb.F + k * c.F - k * d.F;        \
+    o_hl.F = k * a.F + k * bb.F - k * c.F - k * d.F;        \
+    o_hh.F = k * a.F - k * bb.F - k * c.F + k * d.F;
+        HAAR(x) HAAR(y) HAAR(z) HAAR(w)
+#undef HAAR
+        int C = 4 * C4;
+        store4(ll + p * ld_ll + 4 * c4, o_ll);
+        float* hp = hf + p * ld_hf + 4 * c4;
+        store4(hp, o_lh);
+        store4(hp + C, o_hl);
+        store4(hp + 2 * C, o_hh);
+    }
+}
+
+__global__ void __launch_bounds__(256) idwt2_kernel(const float* __restrict__ ll, int ld_ll,
+                                                    const float* __restrict__ hf, int ld_hf, int h, int w, int C4,
+                                                    float* __restrict__ out, int ldo, size_t total) {
+    const float k = haar_tap();
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        int ox = (int)(p % w);
+        size_t q = p / w;
+        int oy = (int)(q % h);
+        int b = (int)(q / h);
+        int C = 4 * C4;
+        float4 vll = load4(ll + p * ld_ll + 4 * c4);
+        const float* hp = hf + p * ld_hf + 4 * c4;
+        float4 vlh = load4(hp), vhl = load4(hp + C), vhh = load4(hp + 2 * C);
+        float4 o00, o01, o10, o11;
+#define IHAAR(F)                                                        \
+    o00.F = k * vll.F + k * vlh.F + k * vhl.F + k * vhh.F;              \
+    o01.F = k * vll.F - k * vlh.F + k * vhl.F - k * vhh.F;              \
+    o10.F = k * vll.F + k * vlh.F - k * vhl.F - k * vhh.F;              \
+    o11.F = k * vll.F - k * vlh.F - k * vhl.F + k * vhh.F;
+        IHAAR(x) IHAAR(y) IHAAR(z) IHAAR(w)
+#undef IHAAR
+        int W2 = 2 * w;
+        float* r0 = out + (((size_t)b * 2 * h + 2 * oy) * W2 + 2 * ox) * ldo + 4 * c4;
+        float* r1 = r0 + (size_t)W2 * ldo;
+        store4(r0, o00);
+        store4(r0 + ldo, o01);
+        store4(r1, o10);
+        store4(r1 + ldo, o11);
+    }
+}
+
+static inline int ew_grid(size_t total, int block = 256) {
+    size_t g = ceil_div_sz(total, block);
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, float* ll, int ld_ll, float* hf,
+                         int ld_hf, uwir_stream_t stream) {
+    UWIR_CHECK(x && ll && hf, "dwt2: null pointer");
+    UWIR_CHECK(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "dwt2: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+    UWIR_CHECK(ldx >= C && ld_ll >= C && ld_hf >= 3 * C && ldx % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
+               "dwt2: bad strides");
+    int h = H / 2, w = W / 2;
+    size_t total = (size_t)B * h * w * (C / 4);
+    hipLaunchKernelGGL(dwt2_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4, h, w,
+                       ll, ld_ll, hf, ld_hf, total);
+    UWIR_LAUNCH_CHECK("dwt2");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf, int B, int h, int w, int C,
+                          float* out, int ldo, uwir_stream_t stream) {
+    UWIR_CHECK(ll && hf && out, "idwt2: null pointer");
+    UWIR_CHECK(B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "idwt2: bad shape");
+    UWIR_CHECK(ldo >= C && ld_ll >= C && ld_hf >= 3 * C && ldo % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
+               "idwt2: bad strides");
+    size_t total = (size_t)B * h * w * (C / 4);
+    hipLaunchKernelGGL(idwt2_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll, hf, ld_hf, h,
+                       w, C / 4, out, ldo, total);
+    UWIR_LAUNCH_CHECK("idwt2");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm2d statistics: per (b, c) mean / biased variance over the n rows of x [B, n, C].
+// Pass 1: block (chunk of rows, channel slab, b) accumulates shifted sums sum(x-K), sum((x-K)^2)
+//         (K = x[b,0,c], keeps fp32 partials well conditioned) -> fp64 partials in workspace.
+// Pass 2: one thread per (b,c) combines partials in a FIXED order (deterministic) in fp64 and
+//         emits the folded affine a*x + s.
+// ------------------------------------------------------------------------------------------
+#define LN_ROWS_PER_BLOCK 256
+#define LN_SLAB_Q 64  // channel quads per block (256 channels)
+
+__global__ void __launch_bounds__(256) ln_partial_kernel(const float* __restrict__ x, int ldx, int n, int C4,
+                                                         double* __restrict__ part, int nchunks) {
+    // threads: tx = quad within slab (0..qs-1), ty = row lane
+    const int qs = min(C4 - blockIdx.y * LN_SLAB_Q, LN_SLAB_Q);
+    const int rl = 256 / LN_SLAB_Q;  // 4 row lanes when slab is full
+    const int tx = threadIdx.x % LN_SLAB_Q, ty = threadIdx.x / LN_SLAB_Q;
+    const int b = blockIdx.z, chunk = blockIdx.x;
+    const int q = blockIdx.y * LN_SLAB_Q + tx;
+    __shared__ float red[2][4][LN_SLAB_Q][4];  // [sum|sq][row lane][quad][4]
+    float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+    if (tx < qs) {
+        const float* base = x + (size_t)b * n * ldx + 4 * q;
+        float4 K = load4(base);
+        int r0 = chunk * LN_ROWS_PER_BLOCK, r1 = min(n, r0 + LN_ROWS_PER_BLOCK);
+        for (int r = r0 + ty; r < r1; r += rl) {
+            float4 v = load4(base + (size_t)r * ldx);
+            float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
+            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+            ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+        }
+    }
+    *reinterpret_cast<float4*>(red[0][ty][tx]) = s;
+    *reinterpret_cast<float4*>(red[1][ty][tx]) = ss;
+    __syncthreads();
+    if (ty == 0 && tx < qs) {
+        int C = 4 * C4;
+        double* o = part + (((size_t)b * nchunks + chunk) * C + 4 * q) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a0 = 0, a1 = 0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                a0 += (double)red[0][l][tx][j];
+                a1 += (double)red[1][l][tx][j];
+            }
+            o[2 * j] = a0;
+            o[2 * j + 1] = a1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restrict__ x, int ldx, int n, int C,
+                                                          const double* __restrict__ part, int nchunks, float eps,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ scale_shift, int ss_ld,
+                                                          float* __restrict__ a_out, float* __restrict__ s_out,
+                                                          float* __restrict__ mean_out,
+                                                          float* __restrict__ pooled_out, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int b = i / C, c = i % C;
+    double s = 0, ss = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const double* p = part + (((size_t)b * nchunks + k) * C + c) * 2;
+        s += p[0];
+        ss += p[1];
+    }
+    double K = (double)x[(size_t)b * n * ldx + c];
+    double md = s / n;
+    double mean = K + md;
+    double var = ss / n - md * md;
+    if (var < 0) var = 0;
+    if (mean_out) mean_out[i] = (float)mean;
+    if (a_out) {
+        double rstd = 1.0 / sqrt(var + (double)eps);
+        double g = gamma[c], bt = beta[c];
+        double sc = 1.0, sh = 0.0;
+        if (scale_shift) {
+            sc = 1.0 + (double)scale_shift[(size_t)b * ss_ld + c];
+            sh = (double)scale_shift[(size_t)b * ss_ld + C + c];
+        }
+        a_out[i] = (float)(rstd * g * sc);
+        s_out[i] = (float)((bt - mean * rstd * g) * sc + sh);
+        // spatial mean of the normalised map: mean((x-mu)*rstd) == 0, so it is beta*(1+scale)+shift
+        if (pooled_out) pooled_out[i] = (float)(bt * sc + sh);
+    }
+}
+
+extern "C" size_t uwir_ln2d_workspace_bytes(int B, int n, int C) {
+    size_t nchunks = ceil_div(n, LN_ROWS_PER_BLOCK);
+    return (size_t)B * nchunks * C * 2 * sizeof(double);
+}
+
+extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+                                const float* beta, const float* scale_shift, int ss_ld, float* a_out, float* s_out,
+                                float* mean_out, float* pooled_out, void* workspace, size_t workspace_bytes,
+                                uwir_stream_t stream) {
+    UWIR_CHECK(x && workspace, "ln2d: null pointer");
+    UWIR_CHECK(B > 0 && n > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0, "ln2d: bad shape B=%d n=%d C=%d ldx=%d",
+               B, n, C, ldx);
+    UWIR_CHECK((a_out && s_out && gamma && beta) || (!a_out && !s_out && mean_out), "ln2d: inconsistent outputs");
+    UWIR_CHECK(!scale_shift || ss_ld >= 2 * C, "ln2d: ss_ld too small");
+    UWIR_CHECK(workspace_bytes >= uwir_ln2d_workspace_bytes(B, n, C), "ln2d: workspace too small");
+    UWIR_CHECK(B <= 65535, "ln2d: batch too large");
+    int nchunks = ceil_div(n, LN_ROWS_PER_BLOCK);
+    int C4 = C / 4;
+    dim3 grid(nchunks, ceil_div(C4, LN_SLAB_Q), B);
+    hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
+                       nchunks);
+    UWIR_LAUNCH_CHECK("ln_partial");
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, C,
+                       (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out,
+                       pooled_out, B);
+    UWIR_LAUNCH_CHECK("ln_finalize");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// ChannelAttention fold (S/wtb.py:24-28,118-119): x + xn*w with xn = a*x + s  ==  x*(1 + a*w) + s*w,
+// i.e. the residual x enters the proj GEMM epilogue through a per-(b,c) affine.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) chan_attn_fold_kernel(const float* __restrict__ a, const float* __restrict__ s,
+                                                             const float* __restrict__ w, float* __restrict__ os,
+                                                             float* __restrict__ oh, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        os[i] = 1.f + a[i] * w[i];
+        oh[i] = s[i] * w[i];
+    }
+}
+
+extern "C" int uwir_chan_attn_fold(const float* a, const float* s, const float* w, float* out_scale, float* out_shift,
+                                   int count, uwir_stream_t stream) {
+    UWIR_CHECK(a && s && w && out_scale && out_shift && count > 0, "chan_attn_fold: bad arguments");
+    hipLaunchKernelGGL(chan_attn_fold_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream, a, s, w,
+                       out_scale, out_shift, count);
+    UWIR_LAUNCH_CHECK("chan_attn_fold");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tiny linear: one wave per output element (b, o)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x, int ldx, int B, int I,
+                                                     const float* __restrict__ W, const float* __restrict__ bias,
+                                                     int O, int act, float* __restrict__ y, int ldy) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) / UWIR_WAVE;
+    int lane = threadIdx.x % UWIR_WAVE;
+    if (wave >= B * O) return;  // whole wave exits together
+    int b = wave / O, o = wave % O;
+    const float* xr = x + (size_t)b * ldx;
+    const float* wr = W + (size_t)o * I;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += UWIR_WAVE) acc = fmaf(xr[i], wr[i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        if (bias) acc += bias[o];
+        y[(size_t)b * ldy + o] = act_apply(acc, act);
+    }
+}
+
+extern "C" int uwir_linear(const float* x, int ldx, int B, int I, const float* W, const float* bias, int O, int act,
+                           float* y, int ldy, uwir_stream_t stream) {
+    UWIR_CHECK(x && W && y, "linear: null pointer");
+    UWIR_CHECK(B > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "linear: bad shape");
+    size_t waves = (size_t)B * O;
+    UWIR_CHECK(waves < (1u << 28), "linear: too many outputs");
+    hipLaunchKernelGGL(linear_kernel, dim3((unsigned)ceil_div_sz(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       B, I, W, bias, O, act, y, ldy);
+    UWIR_LAUNCH_CHECK("linear");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// bilinear resize (align_corners=False, no antialias), NCHW source -> NHWC destination columns
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ src, int B, int M, int hs, int ws,
+                                                       float* __restrict__ dst, int ldd, int hd, int wd, float sy,
+                                                       float sx) {
+    size_t total = (size_t)B * hd * wd * M;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int m = (int)(i % M);
+        size_t p = i / M;
+        int ox = (int)(p % wd);
+        size_t q = p / wd;
+        int oy = (int)(q % hd);
+        int b = (int)(q / hd);
+        // ATen area_pixel_compute_source_index, align_corners=False, cubic=False: clamp below at 0
+        float fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f);
+        float fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f);
+        int y0 = min((int)fy, hs - 1), x0 = min((int)fx, ws - 1);
+        int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+        float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* s = src + ((size_t)b * M + m) * hs * ws;
+        float v00 = s[(size_t)y0 * ws + x0], v01 = s[(size_t)y0 * ws + x1];
+        float v10 = s[(size_t)y1 * ws + x0], v11 = s[(size_t)y1 * ws + x1];
+        float hy = 1.f - ly, hx = 1.f - lx;
+        dst[p * ldd + m] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
+extern "C" int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs, int ws, float* dst, int ldd, int hd,
+                                          int wd, uwir_stream_t stream) {
+    UWIR_CHECK(src && dst, "bilinear: null pointer");
+    UWIR_CHECK(B > 0 && M > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && ldd >= M, "bilinear: bad shape");
+    size_t total = (size_t)B * hd * wd * M;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, B, M, hs, ws,
+                       dst, ldd, hd, wd, (float)hs / (float)hd, (float)ws / (float)wd);
+    UWIR_LAUNCH_CHECK("bilinear");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stem conv 3x3 (tiny Cin) from NCHW input to NHWC features: thread = pixel x 4 output channels
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, int B, int Cin, int H, int W,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   int Co4, float* __restrict__ out, int ldo) {
+    size_t total = (size_t)B * H * W * Co4;
+    int Cout = 4 * Co4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % Co4);
+        size_t p = i / Co4;
+        int ox = (int)(p % W);
+        size_t q = p / W;
+        int oy = (int)(q % H);
+        int b = (int)(q / H);
+        float4 acc = bias ? load4(bias + 4 * c4) : make_float4(0, 0, 0, 0);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                int iy = oy + ky - 1;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    int ix = ox + kx - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    float v = xp[(size_t)iy * W + ix];
+                    float4 wv = load4(w + ((size_t)(ky * 3 + kx) * Cin + ci) * Cout + 4 * c4);
+                    acc.x = fmaf(v, wv.x, acc.x);
+                    acc.y = fmaf(v, wv.y, acc.y);
+                    acc.z = fmaf(v, wv.z, acc.z);
+                    acc.w = fmaf(v, wv.w, acc.w);
+                }
+            }
+        }
+        store4(out + p * ldo + 4 * c4, acc);
+    }
+}
+
+extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
+                                 int Cout, float* out, int ldo, uwir_stream_t stream) {
+    UWIR_CHECK(x_nchw && w && out, "stem: null pointer");
+    UWIR_CHECK(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout % 4 == 0 && ldo >= Cout && ldo % 4 == 0, "stem: bad shape");
+    size_t total = (size_t)B * H * W * (Cout / 4);
+    hipLaunchKernelGGL(stem_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, B, Cin, H, W, w,
+                       bias, Cout / 4, out, ldo);
+    UWIR_LAUNCH_CHECK("stem");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// head: normalise-on-load (final LayerNorm2d affine) -> conv3x3 (zero pad AFTER the norm)
+//       -> + input residual -> clamp.  One wave per output pixel: lanes split (tap, channel-quad)
+//       work, Cout (3) accumulators per lane, wave reduction.  x is NHWC, outputs NCHW.
+// ------------------------------------------------------------------------------------------
+#define HEAD_MAX_COUT 4
+__global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, int ldx, int B, int H, int W, int Cin,
+                                                   const float* __restrict__ a_scale,
+                                                   const float* __restrict__ a_shift, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, int Cout,
+                                                   const float* __restrict__ res, float* __restrict__ out,
+                                                   float* __restrict__ preclamp) {
+    const int lane = threadIdx.x % UWIR_WAVE;
+    const int C4 = Cin / 4;
+    const int items = 9 * C4;  // (tap, quad)
+    size_t npix = (size_t)B * H * W;
+    size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) / UWIR_WAVE;
+    size_t nwaves = ((size_t)gridDim.x * blockDim.x) / UWIR_WAVE;
+    for (size_t p = wave0; p < npix; p += nwaves) {
+        int ox = (int)(p % W);
+        size_t q = p / W;
+        int oy = (int)(q % H);
+        int b = (int)(q / H);
+        float acc[HEAD_MAX_COUT] = {0.f, 0.f, 0.f, 0.f};
+        for (int it = lane; it < items; it += UWIR_WAVE) {
+            int tap = it / C4, c4 = it % C4;
+            int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            float4 v = load4(x + (((size_t)b * H + iy) * W + ix) * ldx + 4 * c4);
+            if (a_scale) {
+                float4 sc = load4(a_scale + (size_t)b * Cin + 4 * c4), sh = load4(a_shift + (size_t)b * Cin + 4 * c4);
+                v.x = fmaf(v.x, sc.x, sh.x);
+                v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z);
+                v.w = fmaf(v.w, sc.w, sh.w);
+            }
+#pragma unroll
+            for (int co = 0; co < HEAD_MAX_COUT; ++co) {
+                if (co < Cout) {
+                    float4 wv = load4(w + ((size_t)co * 9 + tap) * Cin + 4 * c4);
+                    acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < HEAD_MAX_COUT; ++co) {
+            float a = acc[co];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            acc[co] = a;
+        }
+        if (lane < Cout) {
+            float v = acc[0];
+#pragma unroll
+            for (int co = 1; co < HEAD_MAX_COUT; ++co) v = (lane == co) ? acc[co] : v;
+            size_t o = (((size_t)b * Cout + lane) * H + oy) * W + ox;
+            v += (bias ? bias[lane] : 0.f);
+            if (res) v += res[o];
+            if (preclamp) preclamp[o] = v;
+            out[o] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+}
+
+extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* a_scale,
+                                 const float* a_shift, const float* w, const float* bias, int Cout,
+                                 const float* residual_nchw, float* out_nchw, float* preclamp_nchw,
+                                 uwir_stream_t stream) {
+    UWIR_CHECK(x && w && out_nchw, "head: null pointer");
+    UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
+                   ldx % 4 == 0,
+               "head: bad shape (Cout<=%d)", HEAD_MAX_COUT);
+    UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head: a_scale/a_shift must come together");
+    size_t npix = (size_t)B * H * W;
+    size_t blocks = ceil_div_sz(npix, 4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, B, H, W, Cin,
+                       a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw);
+    UWIR_LAUNCH_CHECK("head");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused IR-SDE reverse steps (20 B / element: x, mu, noise, eps in; x out), float4 lanes.
+// Operation order follows the reference expressions so fp32 results agree to rounding.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float euler_one(float x, float mu, float nz, float e, float theta, float sigma,
+                                           float sigma_bar, float dt, float sqrt_dt, float sw, bool has_eps) {
+    float score = -nz / sigma_bar;                                       // sde_utils.py:186-187
+    float drift = (theta * (mu - x) - sw * (sigma * sigma) * score) * dt;  // :177-181 (sw = 1 SDE, 0.5 ODE)
+    float r = x - drift;
+    if (has_eps) r -= sigma * (e * sqrt_dt);                              // :183-184
+    return r;
+}
+
+__global__ void __launch_bounds__(256) sde_euler_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                        const float* __restrict__ noise,
+                                                        const float* __restrict__ eps, float* __restrict__ xo,
+                                                        size_t n4, size_t numel, float theta, float sigma,
+                                                        float sigma_bar, float dt, float sqrt_dt, float sw) {
+    const bool he = eps != nullptr;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = load4(x + 4 * i), m = load4(mu + 4 * i), z = load4(noise + 4 * i);
+        float4 e = he ? load4(eps + 4 * i) : make_float4(0, 0, 0, 0);
+        float4 r;
+        r.x = euler_one(a.x, m.x, z.x, e.x, theta, sigma, sigma_bar, dt, sqrt_dt, sw, he);
+        r.y = euler_one(a.y, m.y, z.y, e.y, theta, sigma, sigma_bar, dt, sqrt_dt, sw, he);
+        r.z = euler_one(a.z, m.z, z.z, e.z, theta, sigma, sigma_bar, dt, sqrt_dt, sw, he);
+        r.w = euler_one(a.w, m.w, z.w, e.w, theta, sigma, sigma_bar, dt, sqrt_dt, sw, he);
+        store4(xo + 4 * i, r);
+    }
+    // tail (numel % 4)
+    size_t t = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t < numel)
+        xo[t] = euler_one(x[t], mu[t], noise[t], he ? eps[t] : 0.f, theta, sigma, sigma_bar, dt, sqrt_dt, sw, he);
+}
+
+__device__ __forceinline__ float post_one(float x, float mu, float nz, float e, float sigma_bar, float expA, float t1,
+                                          float t2, float sd, bool has_eps) {
+    float x0 = (x - mu - sigma_bar * nz) * expA + mu;          // sde_utils.py:245-247
+    float mean = t1 * (x - mu) + t2 * (x0 - mu) + mu;         // :205-214
+    return has_eps ? mean + sd * e : mean;                     // :227-231
+}
+
+__global__ void __launch_bounds__(256) sde_post_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                       const float* __restrict__ noise, const float* __restrict__ eps,
+                                                       float* __restrict__ xo, size_t n4, size_t numel,
+                                                       float sigma_bar, float expA, float t1, float t2, float sd) {
+    const bool he = eps != nullptr;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = load4(x + 4 * i), m = load4(mu + 4 * i), z = load4(noise + 4 * i);
+        float4 e = he ? load4(eps + 4 * i) : make_float4(0, 0, 0, 0);
+        float4 r;
+        r.x = post_one(a.x, m.x, z.x, e.x, sigma_bar, expA, t1, t2, sd, he);
+        r.y = post_one(a.y, m.y, z.y, e.y, sigma_bar, expA, t1, t2, sd, he);
+        r.z = post_one(a.z, m.z, z.z, e.z, sigma_bar, expA, t1, t2, sd, he);
+        r.w = post_one(a.w, m.w, z.w, e.w, sigma_bar, expA, t1, t2, sd, he);
+        store4(xo + 4 * i, r);
+    }
+    size_t t = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t < numel) xo[t] = post_one(x[t], mu[t], noise[t], he ? eps[t] : 0.f, sigma_bar, expA, t1, t2, sd, he);
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int uwir_sde_euler_step(const float* x, const float* mu, const float* noise, const float* eps, float* x_out,
+                                   size_t numel, float theta, float sigma, float sigma_bar, float dt,
+                                   float score_weight, uwir_stream_t stream) {
+    UWIR_CHECK(x && mu && noise && x_out && numel > 0, "sde_euler: null pointer / empty");
+    UWIR_CHECK(aligned16(x) && aligned16(mu) && aligned16(noise) && aligned16(x_out) && (!eps || aligned16(eps)),
+               "sde_euler: pointers must be 16-byte aligned");
+    size_t n4 = numel / 4;
+    int grid = ew_grid(n4 ? n4 : 1);
+    hipLaunchKernelGGL(sde_euler_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mu, noise, eps, x_out, n4,
+                       numel, theta, sigma, sigma_bar, dt, sqrtf(dt), score_weight);
+    UWIR_LAUNCH_CHECK("sde_euler");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_sde_posterior_step(const float* x, const float* mu, const float* noise, const float* eps,
+                                       float* x_out, size_t numel, float sigma_bar, float expA, float term1,
+                                       float term2, float std, uwir_stream_t stream) {
+    UWIR_CHECK(x && mu && noise && x_out && numel > 0, "sde_posterior: null pointer / empty");
+    UWIR_CHECK(aligned16(x) && aligned16(mu) && aligned16(noise) && aligned16(x_out) && (!eps || aligned16(eps)),
+               "sde_posterior: pointers must be 16-byte aligned");
+    size_t n4 = numel / 4;
+    int grid = ew_grid(n4 ? n4 : 1);
+    hipLaunchKernelGGL(sde_post_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mu, noise, eps, x_out, n4,
+                       numel, sigma_bar, expA, term1, term2, std);
+    UWIR_LAUNCH_CHECK("sde_posterior");
+    return UWIR_OK;
+}

@@ -1,0 +1,235 @@
+// 2-D FFT amplitude/phase modulation (S/dwt_fft.py:61-72, S/sffb.py:49-54), NHWC, fp32.
+//
+// Each pass transforms "lines" of L points for a slab of CS consecutive channels entirely in LDS
+// (re/im planes, channel fastest => conflict-free, float4 global traffic):
+//   fwd rows : real x            -> complex workspace          (along W)
+//   fwd cols : complex workspace -> amp = |F|, phase = atan2   (along H)  [self-conjugate bins forced real]
+//   inv cols : amp,phase (polar) -> complex workspace          (along H)
+//   inv rows : complex workspace -> addend + Re(.)             (along W)
+// Powers of two: in-place radix-2 DIT (bit-reversed load, log2 L barrier-separated stages);
+// other lengths: direct DFT against a full twiddle table (O(L^2), correctness path).
+// norm="ortho": each pass scales by 1/sqrt(L).
+#include "common.h"
+
+enum { FFT_FWD_ROWS = 0, FFT_FWD_COLS = 1, FFT_INV_COLS = 2, FFT_INV_ROWS = 3 };
+
+struct FftP {
+    const float* in0;  // x | wre | amp   | wre
+    const float* in1;  // - | wim | phase | wim
+    float* out0;       // wre | amp   | wre | out
+    float* out1;       // wim | phase | wim | -
+    const float* addend;
+    int ld_in, ld_out, ld_add;
+    int H, W, C, L, CS, logL;
+    float norm;
+};
+
+__device__ __forceinline__ int bitrev(int v, int bits) {
+    return bits == 0 ? 0 : (int)(__brev((unsigned)v) >> (32 - bits));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) fft_lines_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = p.L, CS = p.CS, tid = threadIdx.x;
+    constexpr bool ROWS = (MODE == FFT_FWD_ROWS || MODE == FFT_INV_ROWS);
+    constexpr bool INV = (MODE == FFT_INV_COLS || MODE == FFT_INV_ROWS);
+    const bool pow2 = p.logL >= 0;
+    float* re = smem;
+    float* im = re + L * CS;
+    float* re2 = pow2 ? re : im + L * CS;  // second buffer only for the direct DFT
+    float* im2 = pow2 ? im : re2 + L * CS;
+    float* twr = (pow2 ? im + L * CS : im2 + L * CS);
+    float* twi = twr + L;
+
+    // line -> (b, fixed coordinate); point j -> pixel
+    const int line = blockIdx.x;
+    const int c0 = blockIdx.y * CS;
+    const int ncs = min(CS, p.C - c0);  // valid channels in slab (multiple of 4)
+    int b, fixed;
+    if (ROWS) { b = line / p.H; fixed = line % p.H; } else { b = line / p.W; fixed = line % p.W; }
+    auto pixel = [&](int j) -> size_t {
+        return ROWS ? ((size_t)b * p.H + fixed) * p.W + j : ((size_t)b * p.H + j) * p.W + fixed;
+    };
+
+    // twiddles: tw[k] = exp(-+ 2 pi i k / L), k in [0, L)
+    for (int k = tid; k < L; k += 256) {
+        float s, c;
+        sincospif(2.0f * (float)k / (float)L, &s, &c);
+        twr[k] = c;
+        twi[k] = INV ? s : -s;
+    }
+    // load
+    const int q4 = CS / 4;
+    for (int i = tid; i < L * q4; i += 256) {
+        int j = i / q4, q = i % q4;
+        float4 vr = make_float4(0, 0, 0, 0), vi = make_float4(0, 0, 0, 0);
+        if (4 * q < ncs) {
+            size_t px = pixel(j);
+            if (MODE == FFT_FWD_ROWS) {
+                vr = load4(p.in0 + px * p.ld_in + c0 + 4 * q);
+            } else if (MODE == FFT_INV_COLS) {
+                float4 a = load4(p.in0 + px * p.ld_in + c0 + 4 * q), ph = load4(p.in1 + px * p.ld_in + c0 + 4 * q);
+                float s, c;
+                sincosf(ph.x, &s, &c); vr.x = a.x * c; vi.x = a.x * s;
+                sincosf(ph.y, &s, &c); vr.y = a.y * c; vi.y = a.y * s;
+                sincosf(ph.z, &s, &c); vr.z = a.z * c; vi.z = a.z * s;
+                sincosf(ph.w, &s, &c); vr.w = a.w * c; vi.w = a.w * s;
+            } else {
+                vr = load4(p.in0 + px * p.ld_in + c0 + 4 * q);
+                vi = load4(p.in1 + px * p.ld_in + c0 + 4 * q);
+            }
+        }
+        int dst = pow2 ? bitrev(j, p.logL) : j;
+        *reinterpret_cast<float4*>(&re[dst * CS + 4 * q]) = vr;
+        *reinterpret_cast<float4*>(&im[dst * CS + 4 * q]) = vi;
+    }
+    __syncthreads();
+
+    if (pow2) {
+        for (int s = 0; s < p.logL; ++s) {
+            const int half = 1 << s;
+            const int tstep = L >> (s + 1);
+            for (int i = tid; i < (L / 2) * CS; i += 256) {
+                int ch = i % CS, t = i / CS;
+                int grp = t >> s, pos = t & (half - 1);
+                int i0 = ((grp << (s + 1)) + pos) * CS + ch, i1 = i0 + half * CS;
+                float wr = twr[pos * tstep], wi = twi[pos * tstep];
+                float br = re[i1], bi = im[i1];
+                float tr = wr * br - wi * bi, ti = wr * bi + wi * br;
+                float ar = re[i0], ai = im[i0];
+                re[i0] = ar + tr; im[i0] = ai + ti;
+                re[i1] = ar - tr; im[i1] = ai - ti;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int i = tid; i < L * CS; i += 256) {
+            int ch = i % CS, k = i / CS;
+            float sr = 0.f, si = 0.f;
+            int idx = 0;  // (j*k) mod L, updated incrementally
+            for (int j = 0; j < L; ++j) {
+                float wr = twr[idx], wi = twi[idx];
+                float xr = re[j * CS + ch], xi = im[j * CS + ch];
+                sr += wr * xr - wi * xi;
+                si += wr * xi + wi * xr;
+                idx += k;
+                if (idx >= L) idx -= L;
+            }
+            re2[i] = sr;
+            im2[i] = si;
+        }
+        __syncthreads();
+    }
+
+    // store
+    const float nrm = p.norm;
+    const bool fx_self = ROWS ? false : (fixed == 0 || (p.W % 2 == 0 && fixed == p.W / 2));
+    for (int i = tid; i < L * q4; i += 256) {
+        int j = i / q4, q = i % q4;
+        if (4 * q >= ncs) continue;
+        float4 vr = *reinterpret_cast<const float4*>(&re2[j * CS + 4 * q]);
+        float4 vi = *reinterpret_cast<const float4*>(&im2[j * CS + 4 * q]);
+        vr.x *= nrm; vr.y *= nrm; vr.z *= nrm; vr.w *= nrm;
+        vi.x *= nrm; vi.y *= nrm; vi.z *= nrm; vi.w *= nrm;
+        size_t px = pixel(j);
+        if (MODE == FFT_FWD_COLS) {
+            // bins with ky in {0,H/2} and kx in {0,W/2} of a real signal are exactly real: pin Im = +0
+            if (fx_self && (j == 0 || (p.H % 2 == 0 && j == p.H / 2))) vi = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a, ph;
+            a.x = hypotf(vr.x, vi.x); ph.x = atan2f(vi.x, vr.x);
+            a.y = hypotf(vr.y, vi.y); ph.y = atan2f(vi.y, vr.y);
+            a.z = hypotf(vr.z, vi.z); ph.z = atan2f(vi.z, vr.z);
+            a.w = hypotf(vr.w, vi.w); ph.w = atan2f(vi.w, vr.w);
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, a);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, ph);
+        } else if (MODE == FFT_INV_ROWS) {
+            float4 ad = load4(p.addend + px * p.ld_add + c0 + 4 * q);
+            vr.x += ad.x; vr.y += ad.y; vr.z += ad.z; vr.w += ad.w;
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+        } else {
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, vi);
+        }
+    }
+}
+
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+static int pick_cs(int L, bool pow2) {
+    // LDS floats: pow2: 2*L*CS + 2*L ; direct: 4*L*CS + 2*L.  Keep under ~64 KiB.
+    int cs = 16;
+    while (cs > 4 && (size_t)(pow2 ? 2 : 4) * L * cs * 4 + 8 * (size_t)L > 60 * 1024) cs >>= 1;
+    return cs;
+}
+
+template <int MODE>
+static int launch_fft(FftP p, int B, hipStream_t stream) {
+    const bool rows = (MODE == FFT_FWD_ROWS || MODE == FFT_INV_ROWS);
+    p.L = rows ? p.W : p.H;
+    p.logL = ilog2_exact(p.L);
+    const bool pow2 = p.logL >= 0;
+    p.CS = pick_cs(p.L, pow2);
+    p.norm = 1.0f / sqrtf((float)p.L);
+    size_t lds = ((size_t)(pow2 ? 2 : 4) * p.L * p.CS + 2 * (size_t)p.L) * sizeof(float);
+    if (lds > 64 * 1024) return uwir_set_error(UWIR_EUNSUPPORTED, "fft: line length %d too large", p.L);
+    int nlines = rows ? B * p.H : B * p.W;
+    dim3 grid(nlines, ceil_div(p.C, p.CS));
+    hipLaunchKernelGGL((fft_lines_kernel<MODE>), grid, dim3(256), lds, stream, p);
+    UWIR_LAUNCH_CHECK("fft_lines");
+    return UWIR_OK;
+}
+
+extern "C" size_t uwir_fft_workspace_bytes(int B, int H, int W, int C) {
+    return 2 * (size_t)B * H * W * C * sizeof(float);
+}
+
+static int fft_check(int B, int H, int W, int C, const void* ws, size_t ws_bytes) {
+    UWIR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "fft: bad shape");
+    UWIR_CHECK(H <= 1024 && W <= 1024, "fft: H, W must be <= 1024");
+    UWIR_CHECK((long long)B * H < 0x7fffffffLL && (long long)B * W < 0x7fffffffLL, "fft: too many lines");
+    UWIR_CHECK(ws && ws_bytes >= uwir_fft_workspace_bytes(B, H, W, C), "fft: workspace too small");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_fft2_amp_phase(const float* x, int ldx, int B, int H, int W, int C, float* amp, float* phase,
+                                   int ld_out, void* workspace, size_t workspace_bytes, uwir_stream_t stream) {
+    UWIR_CHECK(x && amp && phase, "fft2: null pointer");
+    int rc = fft_check(B, H, W, C, workspace, workspace_bytes);
+    if (rc) return rc;
+    UWIR_CHECK(ldx >= C && ldx % 4 == 0 && ld_out >= C && ld_out % 4 == 0, "fft2: bad strides");
+    float* wre = (float*)workspace;
+    float* wim = wre + (size_t)B * H * W * C;
+    FftP p = {};
+    p.H = H; p.W = W; p.C = C;
+    p.in0 = x; p.in1 = nullptr; p.ld_in = ldx; p.out0 = wre; p.out1 = wim; p.ld_out = C;
+    rc = launch_fft<FFT_FWD_ROWS>(p, B, (hipStream_t)stream);
+    if (rc) return rc;
+    p.in0 = wre; p.in1 = wim; p.ld_in = C; p.out0 = amp; p.out1 = phase; p.ld_out = ld_out;
+    return launch_fft<FFT_FWD_COLS>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int uwir_ifft2_polar_add(const float* amp, const float* phase, int ld_in, const float* addend, int ld_add,
+                                    int B, int H, int W, int C, float* out, int ldo, void* workspace,
+                                    size_t workspace_bytes, uwir_stream_t stream) {
+    UWIR_CHECK(amp && phase && addend && out, "ifft2: null pointer");
+    int rc = fft_check(B, H, W, C, workspace, workspace_bytes);
+    if (rc) return rc;
+    UWIR_CHECK(ld_in >= C && ld_in % 4 == 0 && ld_add >= C && ld_add % 4 == 0 && ldo >= C && ldo % 4 == 0,
+               "ifft2: bad strides");
+    float* wre = (float*)workspace;
+    float* wim = wre + (size_t)B * H * W * C;
+    FftP p = {};
+    p.H = H; p.W = W; p.C = C;
+    p.in0 = amp; p.in1 = phase; p.ld_in = ld_in; p.out0 = wre; p.out1 = wim; p.ld_out = C;
+    rc = launch_fft<FFT_INV_COLS>(p, B, (hipStream_t)stream);
+    if (rc) return rc;
+    p.in0 = wre; p.in1 = wim; p.ld_in = C; p.out0 = out; p.out1 = nullptr; p.ld_out = ldo;
+    p.addend = addend; p.ld_add = ld_add;
+    return launch_fft<FFT_INV_ROWS>(p, B, (hipStream_t)stream);
+}

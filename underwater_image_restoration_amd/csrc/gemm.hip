@@ -1,0 +1,344 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (1x1 convs, k x k convs, linears).
+//
+//   out[m, n] = epi( sum_k A[m, k] * Wt[n, k] ),  m = output pixel (b,oy,ox), k = (ky,kx,c)
+//
+// Tile: 128 (M) x BN (N, 64 or 128) x BK per block of 4 waves; operands go global -> registers
+// (normalise-on-load affine + dtype conversion happen here) -> LDS (padded rows, conflict-free
+// 16-byte fragment reads) -> MFMA.  Register prefetch of tile k+1 overlaps the MFMAs of tile k,
+// one barrier per K tile.  bf16 path: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); fp32 path:
+// v_mfma_f32_16x16x4_f32 (exact fp32, fmaf-chain numerics).  The MFMA is issued "transposed"
+// (weights in the A slot, activations in the B slot) so that each lane ends up holding 4
+// CONSECUTIVE output channels of one pixel: the epilogue (bias, per-sample bias, activation,
+// affine residual, gate blend, depth-to-space scatter) works on 16-byte vectors.
+#include "common.h"
+
+struct GemmP {
+    uwir_gemm_args a;
+    int M, K, tiles_n, nblocks;
+};
+
+template <typename T> struct MmaCfg;
+template <> struct MmaCfg<bf16_t> {
+    static constexpr int BK = 64, EPC = 8, KSTEP = 32, PAD = 8;
+};
+template <> struct MmaCfg<float> {
+    static constexpr int BK = 16, EPC = 4, KSTEP = 4, PAD = 4;
+};
+
+// raw (un-converted) 16-byte-ish chunk as loaded from global
+template <typename TA, int EPC> struct RawChunk;
+template <> struct RawChunk<float, 8> { float4 lo, hi; };
+template <> struct RawChunk<float, 4> { float4 lo; };
+template <> struct RawChunk<bf16_t, 8> { bf16x8 v; };
+
+template <typename TC, typename TA, int BN>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
+    using Cfg = MmaCfg<TC>;
+    constexpr int BM = 128, BK = Cfg::BK, EPC = Cfg::EPC, BKP = BK + Cfg::PAD, CPR = BK / EPC;
+    constexpr int ACH = BM * CPR / 256, BCH = BN * CPR / 256;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N, WM = BM / WAVES_M, TM = WM / 16, TN = 4;
+    constexpr int KSTEPS = BK / Cfg::KSTEP;
+
+    __shared__ __attribute__((aligned(16))) TC sA[2][BM * BKP];
+    __shared__ __attribute__((aligned(16))) TC sB[2][BN * BKP];
+
+    const uwir_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware remap (bijective): blocks sharing an XCD (bid % 8) get a contiguous run of tiles,
+    // so the N-tiles of one M-panel reuse the activation rows out of one L2.
+    int bid = blockIdx.x;
+    {
+        int nwg = p.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+    const int M = p.M, K = p.K, N = g.N, C = g.C;
+    const int OHW = g.OH * g.OW;
+    const bool is1x1 = (g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0);
+
+    const TA* __restrict__ Aptr = (const TA*)g.A;
+    const TC* __restrict__ Wptr = (const TC*)g.Wt;
+
+    // ---- per-thread staging descriptors
+    int a_b[ACH], a_y[ACH], a_x[ACH];
+    bool a_ok[ACH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        int c = tid + 256 * i;
+        int m = m0 + c / CPR;
+        a_ok[i] = m < M;
+        int mm = a_ok[i] ? m : 0;
+        int b = mm / OHW, rem = mm - b * OHW;
+        int oy = rem / g.OW, ox = rem - oy * g.OW;
+        a_b[i] = b;
+        a_y[i] = oy * g.stride - g.pad;
+        a_x[i] = ox * g.stride - g.pad;
+    }
+    RawChunk<TA, EPC> ra[ACH];
+    bool ra_in[ACH];
+    int ra_c[ACH];
+    RawChunk<TC, EPC> rb[BCH];
+
+    auto load_regs = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            int c = tid + 256 * i;
+            int k = kt * BK + (c % CPR) * EPC;
+            bool ok = a_ok[i] && k < K;
+            int tap = 0, ch = k;
+            if (!is1x1) { tap = k / C; ch = k - tap * C; }
+            int ky = tap / g.KW, kx = tap - ky * g.KW;
+            int iy = a_y[i] + ky, ix = a_x[i] + kx;
+            ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            ra_in[i] = ok;
+            ra_c[i] = ch;
+            if (ok) {
+                const TA* src = Aptr + (((size_t)a_b[i] * g.H + iy) * g.W + ix) * g.lda + ch;
+                if constexpr (sizeof(TA) == 4) {
+                    ra[i].lo = *reinterpret_cast<const float4*>(src);
+                    if constexpr (EPC == 8) ra[i].hi = *reinterpret_cast<const float4*>(src + 4);
+                } else {
+                    ra[i].v = *reinterpret_cast<const bf16x8*>(src);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            int c = tid + 256 * i;
+            int n = n0 + c / CPR;
+            int k = kt * BK + (c % CPR) * EPC;
+            if (n < N && k < K) {
+                const TC* src = Wptr + (size_t)n * K + k;
+                if constexpr (sizeof(TC) == 4) rb[i].lo = *reinterpret_cast<const float4*>(src);
+                else rb[i].v = *reinterpret_cast<const bf16x8*>(src);
+            } else {
+                if constexpr (sizeof(TC) == 4) rb[i].lo = make_float4(0, 0, 0, 0);
+                else { bf16x8 z; for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f; rb[i].v = z; }
+            }
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            int c = tid + 256 * i;
+            float v[EPC];
+            if (ra_in[i]) {
+                if constexpr (sizeof(TA) == 4) {
+                    v[0] = ra[i].lo.x; v[1] = ra[i].lo.y; v[2] = ra[i].lo.z; v[3] = ra[i].lo.w;
+                    if constexpr (EPC == 8) { v[4] = ra[i].hi.x; v[5] = ra[i].hi.y; v[6] = ra[i].hi.z; v[7] = ra[i].hi.w; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) v[j] = (float)ra[i].v[j];
+                }
+                if (g.a_scale) {
+                    const float* sc = g.a_scale + (size_t)a_b[i] * C + ra_c[i];
+                    const float* sh = g.a_shift + (size_t)a_b[i] * C + ra_c[i];
+#pragma unroll
+                    for (int j = 0; j < EPC; j += 4) {
+                        float4 s4 = load4(sc + j), h4 = load4(sh + j);
+                        v[j] = fmaf(v[j], s4.x, h4.x);
+                        v[j + 1] = fmaf(v[j + 1], s4.y, h4.y);
+                        v[j + 2] = fmaf(v[j + 2], s4.z, h4.z);
+                        v[j + 3] = fmaf(v[j + 3], s4.w, h4.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) v[j] = 0.f;
+            }
+            TC* dst = &sA[buf][(c / CPR) * BKP + (c % CPR) * EPC];
+            if constexpr (sizeof(TC) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            int c = tid + 256 * i;
+            TC* dst = &sB[buf][(c / CPR) * BKP + (c % CPR) * EPC];
+            if constexpr (sizeof(TC) == 4) *reinterpret_cast<float4*>(dst) = rb[i].lo;
+            else *reinterpret_cast<bf16x8*>(dst) = rb[i].v;
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            if constexpr (sizeof(TC) == 2) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][(wm0 + i * 16 + fr) * BKP + kk * 32 + fq * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn0 + j * 16 + fr) * BKP + kk * 32 + fq * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            } else {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = sA[buf][(wm0 + i * 16 + fr) * BKP + kk * 4 + fq];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = sB[buf][(wn0 + j * 16 + fr) * BKP + kk * 4 + fq];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_regs(kt + 1);
+        compute(kt & 1);
+        if (kt + 1 < nk) store_lds((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per (i, j) tile, pixel m = ..+fr and channels n = ..+fq*4 .. +3
+    const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + wm0 + i * 16 + fr;
+        if (m >= M) continue;
+        int b = m / OHW;
+        size_t out_row = (size_t)m;
+        int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + wn0 + j * 16 + fq * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (g.batch_bias) {
+                float4 t = load4(g.batch_bias + (size_t)b * N + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (g.act != UWIR_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], g.act);
+            }
+            if (g.res) {
+                float4 r = load4(g.res + out_row * g.ldr + n);
+                if (g.res_scale) {
+                    float4 s4 = load4(g.res_scale + (size_t)b * N + n), h4 = load4(g.res_shift + (size_t)b * N + n);
+                    r.x = fmaf(r.x, s4.x, h4.x); r.y = fmaf(r.y, s4.y, h4.y);
+                    r.z = fmaf(r.z, s4.z, h4.z); r.w = fmaf(r.w, s4.w, h4.w);
+                }
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
+            if (g.blend_out) {
+                float4 t = load4(g.blend_t + out_row * g.ld_blend_in + n);
+                float4 f = load4(g.blend_f + out_row * g.ld_blend_in + n);
+                float4 o;
+                o.x = v[0] * t.x + (1.f - v[0]) * f.x;
+                o.y = v[1] * t.y + (1.f - v[1]) * f.y;
+                o.z = v[2] * t.z + (1.f - v[2]) * f.z;
+                o.w = v[3] * t.w + (1.f - v[3]) * f.w;
+                store4(g.blend_out + out_row * g.ld_blend_out + n, o);
+            }
+            if (g.out) {
+                size_t off;
+                if (g.store_mode == 1) {
+                    int qd = n / Cout4, co = n - qd * Cout4;
+                    int dy = qd >> 1, dx = qd & 1;
+                    off = (((size_t)b * 2 * g.OH + 2 * oy + dy) * (2 * g.OW) + 2 * ox + dx) * g.ldo + co;
+                } else {
+                    off = out_row * g.ldo + n;
+                }
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.out_dtype == UWIR_F32) store4((float*)g.out + off, o);
+                else store4((bf16_t*)g.out + off, o);
+            }
+        }
+    }
+}
+
+template <typename TC, typename TA>
+static int launch_gemm(const GemmP& p0, hipStream_t stream) {
+    GemmP p = p0;
+    int bn = p.a.N <= 64 ? 64 : 128;
+    p.tiles_n = ceil_div(p.a.N, bn);
+    long long nb = (long long)ceil_div(p.M, 128) * p.tiles_n;
+    if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
+    p.nblocks = (int)nb;
+    if (bn == 64)
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 64>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 128>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    UWIR_LAUNCH_CHECK("conv_gemm");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) {
+    UWIR_CHECK(args, "conv_gemm: null args");
+    const uwir_gemm_args& g = *args;
+    UWIR_CHECK(g.A && g.Wt && (g.out || g.blend_out), "conv_gemm: null pointer");
+    UWIR_CHECK(g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.N > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0 &&
+                   g.pad >= 0 && g.OH > 0 && g.OW > 0,
+               "conv_gemm: bad geometry");
+    UWIR_CHECK(g.H + 2 * g.pad >= g.KH && g.W + 2 * g.pad >= g.KW &&
+                   g.OH <= (g.H + 2 * g.pad - g.KH) / g.stride + 1 && g.OW <= (g.W + 2 * g.pad - g.KW) / g.stride + 1,
+               "conv_gemm: output size exceeds the convolution's extent");
+    UWIR_CHECK(g.compute == UWIR_F32 || g.compute == UWIR_BF16, "conv_gemm: bad compute dtype");
+    UWIR_CHECK(g.w_dtype == g.compute, "conv_gemm: weight dtype must equal compute dtype");
+    const int epc = g.compute == UWIR_BF16 ? 8 : 4;
+    UWIR_CHECK(g.C % epc == 0 && g.lda % epc == 0 && g.lda >= g.C, "conv_gemm: C and lda must be multiples of %d", epc);
+    UWIR_CHECK(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.Wt & 15) == 0, "conv_gemm: A / Wt must be 16-byte aligned");
+    UWIR_CHECK(g.N % 4 == 0, "conv_gemm: N must be a multiple of 4");
+    UWIR_CHECK((g.a_scale == nullptr) == (g.a_shift == nullptr), "conv_gemm: a_scale/a_shift must come together");
+    UWIR_CHECK((g.res_scale == nullptr) == (g.res_shift == nullptr), "conv_gemm: res_scale/res_shift must come together");
+    UWIR_CHECK(!g.res_scale || g.res, "conv_gemm: res_scale without res");
+    UWIR_CHECK(!g.res || (g.ldr >= g.N && g.ldr % 4 == 0), "conv_gemm: bad ldr");
+    UWIR_CHECK(!g.blend_out || (g.blend_t && g.blend_f && g.ld_blend_in % 4 == 0 && g.ld_blend_out % 4 == 0),
+               "conv_gemm: bad blend arguments");
+    UWIR_CHECK(g.store_mode == 0 || g.store_mode == 1, "conv_gemm: bad store_mode");
+    if (g.out) {
+        UWIR_CHECK(g.out_dtype == UWIR_F32 || g.out_dtype == UWIR_BF16, "conv_gemm: bad out dtype");
+        UWIR_CHECK(g.ldo % 4 == 0, "conv_gemm: ldo must be a multiple of 4");
+        if (g.store_mode == 1) {
+            UWIR_CHECK(g.N % 16 == 0 && g.ldo >= g.N / 4 && !g.res && !g.blend_out,
+                       "conv_gemm: depth-to-space needs N %% 16 == 0 and no residual/blend");
+        } else {
+            UWIR_CHECK(g.ldo >= g.N, "conv_gemm: ldo < N");
+        }
+    }
+    GemmP p;
+    p.a = g;
+    long long M = (long long)g.B * g.OH * g.OW;
+    UWIR_CHECK(M < 0x7fffffffLL, "conv_gemm: M too large");
+    p.M = (int)M;
+    p.K = g.KH * g.KW * g.C;
+    p.tiles_n = 0;
+    p.nblocks = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (g.compute == UWIR_BF16) {
+        if (g.a_dtype == UWIR_F32) return launch_gemm<bf16_t, float>(p, s);
+        if (g.a_dtype == UWIR_BF16) return launch_gemm<bf16_t, bf16_t>(p, s);
+    } else {
+        if (g.a_dtype == UWIR_F32) return launch_gemm<float, float>(p, s);
+    }
+    return uwir_set_error(UWIR_EUNSUPPORTED, "conv_gemm: unsupported (compute, a_dtype) combination");
+}

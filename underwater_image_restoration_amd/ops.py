@@ -1,0 +1,205 @@
+"""Thin Python launchers over the C ABI (include/uwir.h).  Tensors are CUDA(HIP) torch tensors
+used purely as device-memory handles: 2-D ``[rows, ld]`` views (NHWC activations) whose
+``data_ptr()`` / ``stride(0)`` are handed to the kernels.  Nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, BF16, F32, GemmArgs  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _f32(*ts) -> None:
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("expected a float32 tensor")
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Row stride of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("expected a 2-D view with unit inner stride")
+    return t.stride(0)
+
+
+def dwt2(x: torch.Tensor, B: int, H: int, W: int, C: int, ll: torch.Tensor, hf: torch.Tensor) -> None:
+    _f32(x, ll, hf)
+    lib = _lib.load()
+    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _stream()), "dwt2")
+
+
+def idwt2(ll: torch.Tensor, hf: torch.Tensor, B: int, h: int, w: int, C: int, out: torch.Tensor) -> None:
+    _f32(ll, hf, out)
+    lib = _lib.load()
+    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream()), "idwt2")
+
+
+def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
+    return int(_lib.load().uwir_ln2d_workspace_bytes(B, n, C_))
+
+
+def ln2d_affine(x: torch.Tensor, B: int, n: int, C_: int, eps: float, gamma, beta, scale_shift, a_out, s_out,
+                mean_out, pooled_out, workspace: torch.Tensor) -> None:
+    _f32(x, gamma, beta, scale_shift, a_out, s_out, mean_out, pooled_out)
+    lib = _lib.load()
+    ss_ld = 0 if scale_shift is None else _ld(scale_shift)
+    _lib.check(lib.uwir_ln2d_affine(_p(x), _ld(x), B, n, C_, eps, _p(gamma), _p(beta), _p(scale_shift), ss_ld,
+                                    _p(a_out), _p(s_out), _p(mean_out), _p(pooled_out), _p(workspace),
+                                    workspace.numel() * workspace.element_size(), _stream()), "ln2d_affine")
+
+
+def chan_attn_fold(a, s, w, out_scale, out_shift) -> None:
+    _f32(a, s, w, out_scale, out_shift)
+    lib = _lib.load()
+    _lib.check(lib.uwir_chan_attn_fold(_p(a), _p(s), _p(w), _p(out_scale), _p(out_shift), a.numel(), _stream()),
+               "chan_attn_fold")
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, act: int = ACT_NONE) -> None:
+    _f32(x, W, bias, y)
+    lib = _lib.load()
+    B, I = x.shape
+    O = W.shape[0]
+    if W.shape[1] != I or not W.is_contiguous() or y.shape[0] != B or y.shape[1] != O:
+        raise ValueError("linear: shape mismatch")
+    _lib.check(lib.uwir_linear(_p(x), _ld(x), B, I, _p(W), _p(bias), O, act, _p(y), _ld(y), _stream()), "linear")
+
+
+def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *, B: int, H: int, W: int, C_: int,
+              N: int, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, OH: Optional[int] = None,
+              OW: Optional[int] = None, a_scale=None, a_shift=None, bias=None, batch_bias=None, act: int = ACT_NONE,
+              res=None, res_scale=None, res_shift=None, store_mode: int = 0, blend_t=None, blend_f=None,
+              blend_out=None) -> None:
+    """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h."""
+    lib = _lib.load()
+    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out)
+    g = GemmArgs()
+    g.A, g.a_dtype, g.lda = _p(A), _dt(A), _ld(A)
+    g.B, g.H, g.W, g.C = B, H, W, C_
+    g.KH, g.KW, g.stride, g.pad = KH, KW, stride, pad
+    g.OH = OH if OH is not None else (H + 2 * pad - KH) // stride + 1
+    g.OW = OW if OW is not None else (W + 2 * pad - KW) // stride + 1
+    g.a_scale, g.a_shift = _p(a_scale), _p(a_shift)
+    if Wt.dim() != 2 or not Wt.is_contiguous() or Wt.shape[0] != N or Wt.shape[1] != KH * KW * C_:
+        raise ValueError(f"conv_gemm: weight must be contiguous [N, KH*KW*C], got {tuple(Wt.shape)}")
+    g.Wt, g.w_dtype, g.N = _p(Wt), _dt(Wt), N
+    g.bias, g.batch_bias, g.act = _p(bias), _p(batch_bias), act
+    g.res, g.ldr = _p(res), (0 if res is None else _ld(res))
+    g.res_scale, g.res_shift = _p(res_scale), _p(res_shift)
+    g.out = _p(out)
+    g.out_dtype, g.ldo = (0, 0) if out is None else (_dt(out), _ld(out))
+    g.store_mode = store_mode
+    g.blend_t, g.blend_f = _p(blend_t), _p(blend_f)
+    g.ld_blend_in = 0 if blend_t is None else _ld(blend_t)
+    if blend_f is not None and _ld(blend_f) != g.ld_blend_in:
+        raise ValueError("conv_gemm: blend_t / blend_f must share a row stride")
+    g.blend_out, g.ld_blend_out = _p(blend_out), (0 if blend_out is None else _ld(blend_out))
+    g.compute = _dt(Wt)
+    _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
+
+
+def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, out: torch.Tensor, in_scale=None,
+              in_shift=None) -> None:
+    lib = _lib.load()
+    w3, w5, w7 = taps
+    b3, b5, b7 = biases
+    _f32(w3, w5, w7, b3, b5, b7, in_scale, in_shift)
+    _lib.check(lib.uwir_dwconv_ms(_p(x), _dt(x), _ld(x), B, H, W, C_, _p(in_scale), _p(in_shift), _p(w3), _p(w5),
+                                  _p(w7), _p(b3), _p(b5), _p(b7), _p(out), _dt(out), _ld(out), _stream()), "dwconv_ms")
+
+
+def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, o1, o2) -> None:
+    lib = _lib.load()
+    dt = _dt(q)
+    if _dt(k) != dt or _dt(v1) != dt or (v2 is not None and _dt(v2) != dt):
+        raise TypeError("flash_attn: q, k, v must share a dtype")
+    if o2 is not None and _dt(o2) != _dt(o1):
+        raise TypeError("flash_attn: outputs must share a dtype")
+    _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
+                                   0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
+                                   0 if o2 is None else _ld(o2), _dt(o1), _stream()), "flash_attn")
+
+
+def fft_workspace_bytes(B: int, H: int, W: int, C_: int) -> int:
+    return int(_lib.load().uwir_fft_workspace_bytes(B, H, W, C_))
+
+
+def fft2_amp_phase(x, B: int, H: int, W: int, C_: int, amp, phase, workspace) -> None:
+    _f32(x, amp, phase)
+    lib = _lib.load()
+    if _ld(amp) != _ld(phase):
+        raise ValueError("fft2: amp / phase must share a row stride")
+    _lib.check(lib.uwir_fft2_amp_phase(_p(x), _ld(x), B, H, W, C_, _p(amp), _p(phase), _ld(amp), _p(workspace),
+                                       workspace.numel() * workspace.element_size(), _stream()), "fft2_amp_phase")
+
+
+def ifft2_polar_add(amp, phase, addend, B: int, H: int, W: int, C_: int, out, workspace) -> None:
+    _f32(amp, phase, addend, out)
+    lib = _lib.load()
+    if _ld(amp) != _ld(phase):
+        raise ValueError("ifft2: amp / phase must share a row stride")
+    _lib.check(lib.uwir_ifft2_polar_add(_p(amp), _p(phase), _ld(amp), _p(addend), _ld(addend), B, H, W, C_, _p(out),
+                                        _ld(out), _p(workspace), workspace.numel() * workspace.element_size(),
+                                        _stream()), "ifft2_polar_add")
+
+
+def bilinear_nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, hd: int, wd: int) -> None:
+    _f32(src, dst)
+    lib = _lib.load()
+    if not src.is_contiguous() or src.dim() != 4:
+        raise ValueError("bilinear: src must be a contiguous NCHW tensor")
+    B, M, hs, ws = src.shape
+    _lib.check(lib.uwir_bilinear_nchw_to_nhwc(_p(src), B, M, hs, ws, _p(dst), _ld(dst), hd, wd, _stream()), "bilinear")
+
+
+def stem_conv3x3(x_nchw: torch.Tensor, w, bias, out: torch.Tensor) -> None:
+    _f32(x_nchw, w, bias, out)
+    lib = _lib.load()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[-1]
+    _lib.check(lib.uwir_stem_conv3x3(_p(x_nchw), B, Cin, H, W, _p(w), _p(bias), Cout, _p(out), _ld(out), _stream()),
+               "stem_conv3x3")
+
+
+def head_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, a_scale, a_shift, w, bias, Cout: int,
+                 residual_nchw, out_nchw, preclamp_nchw=None) -> None:
+    _f32(x, a_scale, a_shift, w, bias, residual_nchw, out_nchw, preclamp_nchw)
+    lib = _lib.load()
+    _lib.check(lib.uwir_head_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias), Cout,
+                                     _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream()), "head_conv3x3")
+
+
+def sde_euler_step(x, mu, noise, eps, x_out, theta: float, sigma: float, sigma_bar: float, dt: float,
+                   score_weight: float = 1.0) -> None:
+    _f32(x, mu, noise, eps, x_out)
+    lib = _lib.load()
+    _lib.check(lib.uwir_sde_euler_step(_p(x), _p(mu), _p(noise), _p(eps), _p(x_out), x.numel(), theta, sigma,
+                                       sigma_bar, dt, score_weight, _stream()), "sde_euler_step")
+
+
+def sde_posterior_step(x, mu, noise, eps, x_out, sigma_bar: float, expA: float, term1: float, term2: float,
+                       std: float) -> None:
+    _f32(x, mu, noise, eps, x_out)
+    lib = _lib.load()
+    _lib.check(lib.uwir_sde_posterior_step(_p(x), _p(mu), _p(noise), _p(eps), _p(x_out), x.numel(), sigma_bar, expA,
+                                           term1, term2, std, _stream()), "sde_posterior_step")
