@@ -1,0 +1,144 @@
+"""Headline benchmark: restored megapixels / second of the student restoration forward (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W] [--precision bf16|fp32] [--batch 16 --size 256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one forward of the hot path over one batch of synthetic images already resident in HBM.
+N=1 workload = BASELINE.json configs[1]: batch 16 at 256x256, bf16 MFMA compute.
+N>1: images are independent, so every rank runs its own batch (weak scaling, no data-path collective);
+RCCL is used only for the barrier and the MAX-over-ranks of the step time.
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+
+
+def student_flops(batch: int, size: int) -> float:
+    """462*(S/256)^2 + 1401*(S/256)^4 GF per image."""
+    r = size / 256.0
+    return batch * (462e9 * r * r + 1401e9 * r ** 4)
+
+
+def cpu_baseline(mk, sd, size: int, threads: int):
+    """The oracle (CPU restatement of the reference, oracle/student_ref.py) timed on the host cores."""
+    from oracle import student_ref as R
+    from underwater_image_restoration_amd.synth import synth_student_inputs
+    torch.set_num_threads(threads)
+    x, z, m = synth_student_inputs(1, size, size, mk["cond_dim"], mk["num_masks"], mask_hw=(7, 7), seed=1234)
+    t0 = time.time()
+    with torch.no_grad():
+        R.student_forward(sd, x, z, m, blocks_per_level=mk["blocks_per_level"])
+    dt = time.time() - t0
+    return {"value": round(size * size / 1e6 / dt, 6), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": f"1 image {size}x{size} fp32 (oracle/student_ref.py, torch CPU), {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--cpu-size", type=int, default=256)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from underwater_image_restoration_amd import ops
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
+
+    mk = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
+    sd = synth_state_dict(student_param_shapes(**mk), seed=0)
+    model = NAFNetWFIGate(**mk, precision=args.precision)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    x, z, m = synth_student_inputs(args.batch, args.size, args.size, 512, 10, mask_hw=(7, 7), seed=1234 + rank)
+    x, z, m = x.cuda(), z.cuda(), m.cuda()
+
+    def step():
+        return model(x, z, m)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.event_timing(True)  # HIP events around the dominant kernel's launches only (flash attention)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.event_timing(False) if False else None
+    timings = ops.collect_event_timings()
+    ops.event_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        mp = world * args.batch * args.size * args.size / 1e6 * args.steps
+        # dominant kernel: level-0 WTB flash attention (12 heads x hd 16, n = (S/2)^2): most FLOPs of the path
+        n0 = (args.size // 2) ** 2
+        dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
+        roof = None
+        if dom:
+            avg_ms = sum(dom) / len(dom)
+            fl = 4.0 * args.batch * 12 * float(n0) ** 2 * (args.size and 16)  # 4*B*heads*n^2*hd
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.precision]
+            roof = {"bound": "mfma", "kernel": "flash_attn_kernel<hd16,1V> (WTB level 0)", "achieved": round(ach, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}
+        cpu = None
+        if args.cpu_baseline != "skip" and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            cpu = cpu_baseline(mk, sd, args.cpu_size, threads)
+        line = {
+            "metric": "restored megapixels/sec (whole node), student forward", "value": round(mp / elapsed, 4),
+            "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"student NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
+                                   f"{args.precision} MFMA compute (BASELINE configs[1]); z_d synthetic N(0,1) 512-d "
+                                   "(DA-CLIP ViT-B/32 tower not on this path yet), masks (10,7,7)",
+                       "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
+                       "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
+                       "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

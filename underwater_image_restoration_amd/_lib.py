@@ -76,6 +76,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise UwirError(f"{LIB_PATH} is missing: build it with `python -m underwater_image_restoration_amd.build` "
                         "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    # torch ships its own libamdhip64.so; import it FIRST so this library binds to the same HIP runtime
+    # instance (two runtimes in one process => "no ROCm-capable device is detected" in the second).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -17,6 +17,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional HIP-event timing of selected launches (bench.py's roofline leg).  Events are recorded on
+# torch's current stream, which is the stream every kernel of this library is enqueued on.
+_TIMING = {"on": False, "events": []}
+
+
+def event_timing(enable: bool) -> None:
+    _TIMING["on"] = enable
+    _TIMING["events"] = []
+
+
+def collect_event_timings():
+    """-> list of (tag, milliseconds); call after torch.cuda.synchronize()."""
+    out = [(tag, s.elapsed_time(e)) for tag, s, e in _TIMING["events"]]
+    _TIMING["events"] = []
+    return out
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -135,9 +152,16 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
         raise TypeError("flash_attn: q, k, v must share a dtype")
     if o2 is not None and _dt(o2) != _dt(o1):
         raise TypeError("flash_attn: outputs must share a dtype")
+    timed = _TIMING["on"]
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
                                    0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
                                    0 if o2 is None else _ld(o2), _dt(o1), _stream()), "flash_attn")
+    if timed:
+        ev1.record()
+        _TIMING["events"].append((("flash_attn", B, n, heads, hd, 1 if v2 is None else 2, dt), ev0, ev1))
 
 
 def fft_workspace_bytes(B: int, H: int, W: int, C_: int) -> int:
