@@ -107,6 +107,8 @@ typedef struct uwir_gemm_args {
     float* blend_out;
     int ld_blend_out;
     int compute;             /* UWIR_F32: exact-fp32 MFMA; UWIR_BF16: bf16 MFMA, fp32 accumulate */
+    const float* col_scale;  /* optional [N]: value *= col_scale[n] after act, before the residual (used to hand
+                                attention a Q that already carries scale*log2(e), rounded to bf16 only once) */
 } uwir_gemm_args;
 int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);
 
@@ -122,7 +124,9 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
 /* ---- global multi-head attention, flash style (no n x n matrix) ----------------------------
  * S/wtb.py:94-115 (one V) and S/cfc.py:24-39 (one softmax(QK^T/sqrt(hd)) applied to two V's).
  * q,k,v1,v2: [B*n, ld*] matrices (dtype), head h occupies columns [h*hd, (h+1)*hd).
- * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 64. */
+ * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 64.
+ * scale = 1/sqrt(hd) normally; scale == 0 means "q is already multiplied by (1/sqrt(hd))*log2(e)" (the producing
+ * GEMM applied it through col_scale), which saves one bf16 rounding of q. */
 int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1, const void* v2,
                     int ldv2, int dtype, int B, int n, int heads, int hd, float scale, void* o1, int ldo1,
                     void* o2, int ldo2, int out_dtype, uwir_stream_t stream);

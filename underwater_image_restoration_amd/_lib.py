@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("blend_t", vp), ("blend_f", vp), ("ld_blend_in", ci),
         ("blend_out", vp), ("ld_blend_out", ci),
         ("compute", ci),
+        ("col_scale", vp),
     ]
 
 

@@ -14,7 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libuwir_hip.so")
 SOURCES = ["elementwise.hip", "dwconv.hip", "gemm.hip", "attention.hip", "fft.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it every softmax /
+# epilogue touch of an accumulator costs a v_accvgpr_read/write pair.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _stale(target: str, deps) -> bool:
@@ -32,8 +35,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + headers + [os.path.abspath(__file__)]):
+            # attention: fmaxf on MFMA outputs would otherwise get a canonicalising v_max per element
+            extra = ["-fno-honor-nans"] if src == "attention.hip" else []
+            cmd = [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

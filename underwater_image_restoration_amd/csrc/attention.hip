@@ -18,7 +18,7 @@ struct AttnP {
     void* o[2];
     int ldq, ldk, ldv[2], ldo[2];
     int n, heads, hd, out_dtype;
-    float c;  // scale * log2(e)
+    float c;  // scale * log2(e); 1 when q is pre-scaled
 };
 
 #define AT_KT 64
@@ -37,6 +37,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     constexpr int DG = (DV + 31) / 32;         // 32-row d groups of O^T
     constexpr int NKC = (KT * (HD / 4)) / 256; // K chunks (4 elements) per thread per tile
     constexpr int QPR = HD / 4;                // chunks per key row
+    // spare O^T row: a ones-row in V^T makes the PV MFMA sum P for free.  bf16 path only: the fp32 parity path
+    // keeps the pairwise VALU sums (a 4096-long sequential fp32 chain costs ~3e-5 of accuracy).
+    constexpr bool SUMROW = BF && (DV % 32) != 0;
     using C4 = typename Chunk4<T>::type;
 
     __shared__ __attribute__((aligned(16))) T sK[2][KT * KSTR];
@@ -58,7 +61,8 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     for (int i = tid; i < 2 * DG * 32 * VSTR; i += 256) (&sVt[0][0])[i] = (T)0.f;
     for (int i = tid; i < 2 * KT * KSTR; i += 256) (&sK[0][0])[i] = (T)0.f;
 
-    // ---- Q fragments straight from global
+    // ---- Q fragments straight from global, pre-multiplied by c = scale*log2(e): the QK^T MFMA then
+    //      yields scores directly in the log2 domain and exp2 needs no per-element multiply.
     constexpr int KS = BF ? HD / 16 : HD / 2;
     typedef typename std::conditional<BF, bf16x8, float>::type QF;
     QF qf[KS];
@@ -76,7 +80,8 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
                     bf16x4 v;
                     if (qok && d < hd) v = *reinterpret_cast<const bf16x4*>(qrow + d);
                     else { v[0] = v[1] = v[2] = v[3] = (bf16_t)0.f; }
-                    f[4 * half] = v[0]; f[4 * half + 1] = v[1]; f[4 * half + 2] = v[2]; f[4 * half + 3] = v[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[4 * half + e] = c == 1.f ? v[e] : (bf16_t)((float)v[e] * c);
                 }
                 qf[ks] = f;
             }
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 int d = 2 * ks + lh;
-                qf[ks] = (qok && d < hd) ? (float)qrow[d] : 0.f;
+                qf[ks] = (qok && d < hd) ? (float)qrow[d] * c : 0.f;
             }
         }
     }
@@ -138,12 +143,127 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     for (int g = 0; g < DG; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[g][r] = 0.f;
-    float m_run = -1e30f;  // running max in scaled (log2) units
-    float l_run = 0.f;     // this lane's partial denominator (its 16 keys of every 32)
+    // Running max m (log2 units) enters the scores through ONE extra QK^T MFMA k-step instead of
+    // 16 VALU subtractions per block: K is extended by constant columns [1, 1, mask] and Q by
+    // [-m_hi, -m_lo, -BIG] (m split in two bf16 terms, exact in the fp32 accumulate), so the MFMA
+    // emits c*S - m directly, keys >= n are pushed to -BIG (exp2 -> 0) and the numerator is a bare exp2.
+    float m_eff = 0.f;
+    QF qext;
+    if constexpr (BF) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qext[j] = (bf16_t)0.f;
+        qext[2] = (bf16_t)(-30000.f);
+    } else {
+        qext = lh == 0 ? 0.f : -1e30f;
+    }
+    float l_run = 0.f;     // this lane's partial denominator (unused when the ones-row provides it)
+    bool first = true;     // the first block adopts its own max unconditionally (wave-uniform)
     constexpr float THR = BF ? 4.f : 0.f;
+    const int kbase = lq * KSTR + (BF ? 8 : 1) * lh;
+    const int vbase = lq * VSTR + (BF ? 8 * lh : 0);
+
+    auto block = [&](const int kb, const int buf, const int k0) {
+        const bool masked = (k0 + kb * 32 + lq) >= n;
+        // ---- S^T = K . Q^T - m
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][kb * 32 * KSTR + kbase + 16 * ks]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            bf16x8 kext;
+            const bf16_t one = (bf16_t)(lh == 0 ? 1.f : 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kext[j] = (bf16_t)0.f;
+            kext[0] = one;
+            kext[1] = one;
+            kext[2] = (bf16_t)((lh == 0 && masked) ? 1.f : 0.f);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kext, qext, s, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float kf = sK[buf][kb * 32 * KSTR + kbase + 2 * ks];
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[ks], s, 0, 0, 0);
+            }
+            const float kext = lh == 0 ? 1.f : (masked ? 1.f : 0.f);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kext, qext, s, 0, 0, 0);
+        }
+        // ---- online softmax, deferred max: rescale only when the block max exceeds the running max by > THR
+        float mxa = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mxa = fmaxf(fmaxf(mxa, s[r]), s[r + 1]);
+        {
+            unsigned u = __float_as_uint(mxa);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mxa = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (first || __any(mxa > THR)) {
+            const float delta = first ? mxa : fmaxf(mxa, 0.f);
+            float m_new = m_eff + delta;
+            if constexpr (BF) {
+                const bf16_t hi = (bf16_t)m_new;
+                const bf16_t lo = (bf16_t)(m_new - (float)hi);
+                m_new = (float)hi + (float)lo;  // exactly what the next MFMA will subtract
+                qext[0] = (bf16_t)(-(float)hi);
+                qext[1] = (bf16_t)(-(float)lo);
+            } else {
+                if (lh == 0) qext = -m_new;
+            }
+            const float dlt = m_new - m_eff;
+            m_eff = m_new;
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-dlt);
+            first = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] -= dlt;
+            l_run *= alpha;
+#pragma unroll
+            for (int g = 0; g < DG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[g][r] *= alpha;
+        }
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
+        if constexpr (!SUMROW) {
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { l0 += pr[r]; l1 += pr[r + 1]; }
+            l_run += l0 + l1;
+        }
+        // ---- O^T += V^T . P   (with SUMROW, row DV of V^T is all ones, so O^T[DV][q] accumulates sum_k P)
+        if constexpr (BF) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
+#pragma unroll
+                for (int g = 0; g < DG; ++g) {
+                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][g * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
+                    O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int g = 0; g < DG; ++g) {
+                    float vf = sVt[buf][g * 32 * VSTR + vbase + key];
+                    O[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], O[g], 0, 0, 0);
+                }
+            }
+        }
+    };
 
     const int ntiles = (n + KT - 1) / KT;
     __syncthreads();
+    if constexpr (SUMROW) {  // ones row (after the zero fill, before the first tile lands)
+        for (int i = tid; i < 2 * VSTR; i += 256) sVt[i / VSTR][DV * VSTR + (i % VSTR)] = (T)1.f;
+    }
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -152,94 +272,19 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
         const int buf = t & 1;
         if (t + 1 < ntiles) load_tile((t + 1) * KT);
         const int k0 = t * KT;
-        const bool tail = k0 + KT > n;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (k0 + kb * 32 >= n) break;  // whole 32-key block out of range (wave-uniform)
-            // ---- S^T = K . Q^T
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            if constexpr (BF) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][(kb * 32 + lq) * KSTR + 16 * ks + 8 * lh]);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    float kf = sK[buf][(kb * 32 + lq) * KSTR + 2 * ks + lh];
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[ks], s, 0, 0, 0);
-                }
-            }
-            if (tail) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key >= n) s[r] = -INFINITY;
-                }
-            }
-            // ---- online softmax (deferred max)
-            float mx = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            {
-                unsigned u = __float_as_uint(mx);
-                auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            float mxs = mx * c;
-            if (__any(mxs > m_run + THR)) {
-                float m_new = fmaxf(m_run, mxs);
-                float alpha = exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int g = 0; g < DG; ++g)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) O[g][r] *= alpha;
-            }
-            float pr[16];
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -m_run));
-                lsum += pr[r];
-            }
-            l_run += lsum;
-            // ---- O^T += V^T . P
-            if constexpr (BF) {
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    bf16x8 pb;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
-#pragma unroll
-                    for (int g = 0; g < DG; ++g) {
-                        bf16x8 vf = *reinterpret_cast<const bf16x8*>(
-                            &sVt[buf][(g * 32 + lq) * VSTR + kb * 32 + 16 * ss + 8 * lh]);
-                        O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-#pragma unroll
-                    for (int g = 0; g < DG; ++g) {
-                        float vf = sVt[buf][(g * 32 + lq) * VSTR + key];
-                        O[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], O[g], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        block(0, buf, k0);
+        if (k0 + 32 < n) block(1, buf, k0);
         if (t + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- finish: combine the two half-wave denominators, normalise, store
-    {
+    // ---- finish: denominators (ones-row or summed halves), normalise, store
+    if constexpr (SUMROW) {
+        constexpr int lr = DV % 32, rl = (lr & 3) + 4 * (lr >> 3), hl = (lr >> 2) & 1;
+        unsigned u = __float_as_uint(O[DG - 1][rl]);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        l_run = __uint_as_float(sw[hl]);
+    } else {
         unsigned u = __float_as_uint(l_run);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -302,7 +347,8 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     p.o[0] = o1; p.o[1] = o2;
     p.ldq = ldq; p.ldk = ldk; p.ldv[0] = ldv1; p.ldv[1] = ldv2; p.ldo[0] = ldo1; p.ldo[1] = ldo2;
     p.n = n; p.heads = heads; p.hd = hd; p.out_dtype = out_dtype;
-    p.c = scale * 1.4426950408889634f;
+    UWIR_CHECK(scale >= 0.f, "flash_attn: negative scale");
+    p.c = scale == 0.f ? 1.f : scale * 1.4426950408889634f;
     int nv = v2 ? 2 : 1;
     if (dtype == UWIR_BF16) return launch_attn<bf16_t>(p, nv, B, (hipStream_t)stream);
     return launch_attn<float>(p, nv, B, (hipStream_t)stream);

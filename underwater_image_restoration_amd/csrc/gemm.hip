@@ -240,6 +240,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], g.act);
             }
+            if (g.col_scale) {
+                float4 t = load4(g.col_scale + n);
+                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
+            }
             if (g.res) {
                 float4 r = load4(g.res + out_row * g.ldr + n);
                 if (g.res_scale) {

@@ -106,10 +106,10 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
               N: int, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, OH: Optional[int] = None,
               OW: Optional[int] = None, a_scale=None, a_shift=None, bias=None, batch_bias=None, act: int = ACT_NONE,
               res=None, res_scale=None, res_shift=None, store_mode: int = 0, blend_t=None, blend_f=None,
-              blend_out=None) -> None:
+              blend_out=None, col_scale=None) -> None:
     """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h."""
     lib = _lib.load()
-    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out)
+    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale)
     g = GemmArgs()
     g.A, g.a_dtype, g.lda = _p(A), _dt(A), _ld(A)
     g.B, g.H, g.W, g.C = B, H, W, C_
@@ -132,6 +132,7 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
         raise ValueError("conv_gemm: blend_t / blend_f must share a row stride")
     g.blend_out, g.ld_blend_out = _p(blend_out), (0 if blend_out is None else _ld(blend_out))
     g.compute = _dt(Wt)
+    g.col_scale = _p(col_scale)
     _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
 
 

@@ -23,6 +23,7 @@ from . import ops
 from .synth import student_param_shapes
 
 _EPS = 1e-5
+_LOG2E = 1.4426950408889634
 
 
 class _Holder(nn.Module):
@@ -140,6 +141,10 @@ class NAFNetWFIGate(nn.Module):
             b["dw_t"] = tuple(taps(sd[h + f"dw_branches.{i}.weight"]) for i in range(3))
             b["dw_b"] = tuple(vec(sd[h + f"dw_branches.{i}.bias"]) for i in range(3))
             b["merge_w"], b["merge_b"] = mat(sd[h + "dw_merge.weight"]), vec(sd[h + "dw_merge.bias"])
+            # q columns leave the GEMM already multiplied by (1/sqrt(hd))*log2(e) (attention works in exp2)
+            cs = torch.ones(3 * Cw, device=dev, dtype=f32)
+            cs[:Cw] = _LOG2E / math.sqrt(Cw // 12)
+            b["merge_cs"] = cs
             b["proj_w"], b["proj_b"] = mat(sd[h + "proj.weight"]), vec(sd[h + "proj.bias"])
             b["ca_w0"], b["ca_b0"] = sd[h + "channel_attn.net.0.weight"].to(f32).contiguous(), vec(sd[h + "channel_attn.net.0.bias"])
             b["ca_w1"], b["ca_b1"] = sd[h + "channel_attn.net.2.weight"].to(f32).contiguous(), vec(sd[h + "channel_attn.net.2.bias"])
@@ -169,6 +174,9 @@ class NAFNetWFIGate(nn.Module):
             # hf_sum = lh+hl+hh (model.py:37) folded into the weights: W @ (a+b+c) = [W|W|W] @ [a;b;c]
             b["qvt_w"] = torch.cat([wq.repeat(1, 3), wvt.repeat(1, 3)], dim=0).to(wdt).contiguous()
             b["qvt_b"] = torch.cat([vec(sd[f + "q_conv.bias"]), vec(sd[f + "vt_conv.bias"])]).contiguous()
+            cs = torch.ones(2 * Cc, device=dev, dtype=f32)
+            cs[:Cc] = _LOG2E / math.sqrt(Cc // 4)
+            b["qvt_cs"] = cs
             b["kvf_w"] = torch.cat([sd[f + "k_conv.weight"].reshape(Cc, Cc), sd[f + "vf_conv.weight"].reshape(Cc, Cc)],
                                    dim=0).to(wdt).contiguous()
             b["kvf_b"] = torch.cat([vec(sd[f + "k_conv.bias"]), vec(sd[f + "vf_conv.bias"])]).contiguous()
@@ -256,10 +264,11 @@ class NAFNetWFIGate(nn.Module):
         ms = buf("ms", 9 * Cw, adt)
         ops.dwconv_ms(qkv_base, B, h, w, 3 * Cw, bp["dw_t"], bp["dw_b"], ms)
         qkv = buf("qkv", 3 * Cw, adt)
-        ops.conv_gemm(ms, bp["merge_w"], qkv, B=B, H=h, W=w, C_=9 * Cw, N=3 * Cw, bias=bp["merge_b"])
+        ops.conv_gemm(ms, bp["merge_w"], qkv, B=B, H=h, W=w, C_=9 * Cw, N=3 * Cw, bias=bp["merge_b"],
+                      col_scale=bp["merge_cs"])
         att = buf("att", Cw, adt)
         hd = Cw // 12
-        ops.flash_attn(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], None, B, n, 12, hd, 1.0 / math.sqrt(hd), att, None)
+        ops.flash_attn(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], None, B, n, 12, hd, 0.0, att, None)
         x1 = buf("x1", Cw)
         ops.conv_gemm(att, bp["proj_w"], x1, B=B, H=h, W=w, C_=Cw, N=Cw, bias=bp["proj_b"], res=hf, res_scale=rs, res_shift=rh)
         a2, s2 = small("a2", Cw), small("s2", Cw)
@@ -292,10 +301,10 @@ class NAFNetWFIGate(nn.Module):
 
         # ---------------- CrossFrequencyConditioner (cfc.py:24-39)
         qvt, kvf = buf("qvt", 2 * Cc, adt), buf("kvf", 2 * Cc, adt)
-        ops.conv_gemm(hf_out, bp["qvt_w"], qvt, B=B, H=h, W=w, C_=Cw, N=2 * Cc, bias=bp["qvt_b"])
+        ops.conv_gemm(hf_out, bp["qvt_w"], qvt, B=B, H=h, W=w, C_=Cw, N=2 * Cc, bias=bp["qvt_b"], col_scale=bp["qvt_cs"])
         ops.conv_gemm(lf, bp["kvf_w"], kvf, B=B, H=h, W=w, C_=Cc, N=2 * Cc, bias=bp["kvf_b"])
         hd2 = Cc // 4
-        ops.flash_attn(qvt[:, :Cc], kvf[:, :Cc], qvt[:, Cc:], kvf[:, Cc:], B, n, 4, hd2, 1.0 / math.sqrt(hd2),
+        ops.flash_attn(qvt[:, :Cc], kvf[:, :Cc], qvt[:, Cc:], kvf[:, Cc:], B, n, 4, hd2, 0.0,
                        gate_in[:, :Cc], gate_in[:, Cc:2 * Cc])
 
         # ---------------- WFIGate (wfi_gate.py:29-45)
@@ -315,7 +324,7 @@ class NAFNetWFIGate(nn.Module):
             taps.update(hf=nchw(hf_out, Cw), lf=nchw(lf, Cc), t_out=nchw(gate_in, Cc),
                         f_out=nchw(gate_in[:, Cc:], Cc), merged=nchw(merged, Cc), alpha=alpha.permute(0, 3, 1, 2),
                         out=out[:, :Cc].reshape(B, h2, w2, Cc).permute(0, 3, 1, 2).clone(),
-                        wtb=dict(qkv_base=nchw(qkv_base, 3 * Cw), qkv=nchw(qkv, 3 * Cw), att=nchw(att, Cw),
+                        wtb=dict(qkv_base=nchw(qkv_base, 3 * Cw), att=nchw(att, Cw),
                                  x1=nchw(x1, Cw)),
                         sffb=dict(spatial=nchw(spatial, Cc), freq=None))
         return alpha
