@@ -31,6 +31,76 @@ template <> struct RawChunk<float, 8> { float4 lo, hi; };
 template <> struct RawChunk<float, 4> { float4 lo; };
 template <> struct RawChunk<bf16_t, 8> { bf16x8 v; };
 
+// ---- shared epilogue: the lane holds, per (i, j) MFMA tile, pixel m = m_base + i*16 + fr and the 4
+//      consecutive channels n = n_base + j*16 + fq*4 .. +3
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], int M, int m_base,
+                                              int n_base, int fr, int fq) {
+    const int N = g.N;
+    const int OHW = g.OH * g.OW;
+    const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m_base + i * 16 + fr;
+        if (m >= M) continue;
+        int b = m / OHW;
+        size_t out_row = (size_t)m;
+        int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n_base + j * 16 + fq * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (g.batch_bias) {
+                float4 t = load4(g.batch_bias + (size_t)b * N + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (g.act != UWIR_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], g.act);
+            }
+            if (g.col_scale) {
+                float4 t = load4(g.col_scale + n);
+                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
+            }
+            if (g.res) {
+                float4 r = load4(g.res + out_row * g.ldr + n);
+                if (g.res_scale) {
+                    float4 s4 = load4(g.res_scale + (size_t)b * N + n), h4 = load4(g.res_shift + (size_t)b * N + n);
+                    r.x = fmaf(r.x, s4.x, h4.x); r.y = fmaf(r.y, s4.y, h4.y);
+                    r.z = fmaf(r.z, s4.z, h4.z); r.w = fmaf(r.w, s4.w, h4.w);
+                }
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
+            if (g.blend_out) {
+                float4 t = load4(g.blend_t + out_row * g.ld_blend_in + n);
+                float4 f = load4(g.blend_f + out_row * g.ld_blend_in + n);
+                float4 o;
+                o.x = v[0] * t.x + (1.f - v[0]) * f.x;
+                o.y = v[1] * t.y + (1.f - v[1]) * f.y;
+                o.z = v[2] * t.z + (1.f - v[2]) * f.z;
+                o.w = v[3] * t.w + (1.f - v[3]) * f.w;
+                store4(g.blend_out + out_row * g.ld_blend_out + n, o);
+            }
+            if (g.out) {
+                size_t off;
+                if (g.store_mode == 1) {
+                    int qd = n / Cout4, co = n - qd * Cout4;
+                    int dy = qd >> 1, dx = qd & 1;
+                    off = (((size_t)b * 2 * g.OH + 2 * oy + dy) * (2 * g.OW) + 2 * ox + dx) * g.ldo + co;
+                } else {
+                    off = out_row * g.ldo + n;
+                }
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.out_dtype == UWIR_F32) store4((float*)g.out + off, o);
+                else store4((bf16_t*)g.out + off, o);
+            }
+        }
+    }
+}
+
+
 template <typename TC, typename TA, int BN>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     using Cfg = MmaCfg<TC>;
@@ -217,68 +287,108 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, per (i, j) tile, pixel m = ..+fr and channels n = ..+fq*4 .. +3
-    const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int m = m0 + wm0 + i * 16 + fr;
-        if (m >= M) continue;
-        int b = m / OHW;
-        size_t out_row = (size_t)m;
-        int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = n0 + wn0 + j * 16 + fq * 4;
-            if (n >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-            if (g.batch_bias) {
-                float4 t = load4(g.batch_bias + (size_t)b * N + n);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (g.act != UWIR_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], g.act);
-            }
-            if (g.col_scale) {
-                float4 t = load4(g.col_scale + n);
-                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
-            }
-            if (g.res) {
-                float4 r = load4(g.res + out_row * g.ldr + n);
-                if (g.res_scale) {
-                    float4 s4 = load4(g.res_scale + (size_t)b * N + n), h4 = load4(g.res_shift + (size_t)b * N + n);
-                    r.x = fmaf(r.x, s4.x, h4.x); r.y = fmaf(r.y, s4.y, h4.y);
-                    r.z = fmaf(r.z, s4.z, h4.z); r.w = fmaf(r.w, s4.w, h4.w);
-                }
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            }
-            if (g.blend_out) {
-                float4 t = load4(g.blend_t + out_row * g.ld_blend_in + n);
-                float4 f = load4(g.blend_f + out_row * g.ld_blend_in + n);
-                float4 o;
-                o.x = v[0] * t.x + (1.f - v[0]) * f.x;
-                o.y = v[1] * t.y + (1.f - v[1]) * f.y;
-                o.z = v[2] * t.z + (1.f - v[2]) * f.z;
-                o.w = v[3] * t.w + (1.f - v[3]) * f.w;
-                store4(g.blend_out + out_row * g.ld_blend_out + n, o);
-            }
-            if (g.out) {
-                size_t off;
-                if (g.store_mode == 1) {
-                    int qd = n / Cout4, co = n - qd * Cout4;
-                    int dy = qd >> 1, dx = qd & 1;
-                    off = (((size_t)b * 2 * g.OH + 2 * oy + dy) * (2 * g.OW) + 2 * ox + dx) * g.ldo + co;
-                } else {
-                    off = out_row * g.ldo + n;
-                }
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (g.out_dtype == UWIR_F32) store4((float*)g.out + off, o);
-                else store4((bf16_t*)g.out + off, o);
-            }
-        }
-    }
+    gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
 }
+
+// ------------------------------------------------------------------------------------------
+// Fast path: plain bf16 x bf16 GEMM (1x1 conv, bf16 activations, no prologue affine, K % 64 == 0).
+// Both operands stream global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4): no staging
+// registers, no conversion pass.  The LDS image is lane-linear ([row][8 chunks of 16 B], 128-B rows),
+// so the bank-conflict swizzle (chunk ^= row & 7) is applied on the per-lane SOURCE address and
+// again on the fragment read.  One barrier per K tile: tile t+1 is in flight while tile t feeds
+// 32 v_mfma_f32_16x16x32_bf16 per wave.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
+    constexpr int BM = 128, BN = 128, BK = 64, TM = 4, TN = 4;
+    constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];  // [buf][A|B]
+
+    const uwir_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        int nwg = p.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+    const int M = p.M, K = p.K, N = g.N;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt;
+
+    // staging: wave w owns rows [32w, 32w+32) of both tiles, 4 LDS-DMA pieces of 8 rows each per operand.
+    // lane -> (row-in-piece = lane/8, LDS chunk = lane%8) reads GLOBAL chunk (lane%8) ^ (row & 7).
+    const int prow = lane >> 3, pch = lane & 7;
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = wave * 32 + i * 8 + prow;
+        int gch = pch ^ (r & 7);
+        int am = min(m0 + r, M - 1), bn = min(n0 + r, N - 1);  // clamp: rows past the edge are never stored
+        a_src[i] = A + (size_t)am * g.lda + gch * 8;
+        b_src[i] = Wt + (size_t)bn * K + gch * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * 2 * TILE_BYTES + (wave * 32) * 128;
+        char* lb = la + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(la + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(lb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a tile: row*128 + ((chunk ^ (row&7)) * 16); row&7 == fr&7 for every i
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = (wm0 + i * 16 + fr) * 128;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = (wn0 + j * 16 + fr) * 128;
+    const int sw = fr & 7;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const char* la = smem + buf * 2 * TILE_BYTES;
+        const char* lb = la + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+            const int ch = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(la + a_off[i] + ch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + b_off[j] + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
+}
+
+static bool glds_eligible(const uwir_gemm_args& g, int K) {
+    return g.compute == UWIR_BF16 && g.a_dtype == UWIR_BF16 && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 &&
+           !g.a_scale && K % 64 == 0 && g.N > 64 && g.lda % 8 == 0;
+}
+
 
 template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
@@ -288,6 +398,11 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     long long nb = (long long)ceil_div(p.M, 128) * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
+    if (glds_eligible(p.a, p.K)) {
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3(p.nblocks), dim3(256), 0, stream, p);
+        UWIR_LAUNCH_CHECK("conv_gemm(glds)");
+        return UWIR_OK;
+    }
     if (bn == 64)
         hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 64>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else
