@@ -92,9 +92,66 @@ def dwt_case() -> None:
     np.savez_compressed(os.path.join(HERE, "dwt.npz"), **store)
 
 
+
+
+def sde_case() -> None:
+    """IRSDE tables + short trajectories from the reference's own sde_utils.py (loaded as a single file; its only
+    torchvision use is save_image under save_states=True, so an empty stub module satisfies the import)."""
+    import importlib.util
+    import types
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tv.utils = tvu
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    spec = importlib.util.spec_from_file_location(
+        "ref_sde_utils", "/root/reference/legacy/third_party/universal-image-restoration/utils/sde_utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    store = {}
+    for sched in ("cosine", "linear", "constant"):
+        sde = mod.IRSDE(max_sigma=50, T=100, schedule=sched, eps=0.005)
+        for nm in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars"):
+            store[f"{sched}_{nm}"] = getattr(sde, nm).numpy()
+        store[f"{sched}_dt"] = np.float32(float(sde.dt))
+    # trajectories with a closed-form stand-in for the score network and recorded noise
+    g = torch.Generator().manual_seed(77)
+    mu = torch.rand(2, 3, 8, 8, generator=g)
+    sde = mod.IRSDE(max_sigma=50, T=100, schedule="cosine", eps=0.005)
+    sde.set_mu(mu)
+    sde.set_model(lambda x, mu_, t, **kw: 0.3 * (x - mu_) + 0.01 * torch.sin(x * 7 + float(t)))
+    xt = mu + torch.randn(mu.shape, generator=g) * sde.max_sigma
+    store["traj_mu"], store["traj_xt"] = mu.numpy(), xt.numpy()
+    real_randn_like = torch.randn_like
+    for mode in ("sde", "posterior", "ode"):
+        tape = []
+
+        def rec(t, *a, **k):
+            z = real_randn_like(t, *a, **k)
+            tape.append(z.clone())
+            return z
+        torch.manual_seed(5)
+        torch.randn_like = rec
+        try:
+            if mode == "sde":
+                out = sde.reverse_sde(xt, T=6)
+            elif mode == "posterior":
+                out = sde.reverse_posterior(xt, T=6)
+            else:
+                out = sde.reverse_ode(xt, T=6)
+        finally:
+            torch.randn_like = real_randn_like
+        store[f"traj_{mode}_out"] = out.numpy()
+        if tape:
+            store[f"traj_{mode}_tape"] = torch.stack(tape).numpy()
+    np.savez_compressed(os.path.join(HERE, "sde.npz"), **store)
+    print("sde: dt", float(sde.dt), "sigma_bar[100]", float(sde.sigma_bars[100]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     dwt_case()
     for name, cfg in STUDENT_CASES.items():
         student_case(name, cfg)
+    sde_case()
