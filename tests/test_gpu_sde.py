@@ -54,7 +54,8 @@ def test_full_100_step_loop_matches_oracle(sde_mod, mode, sched):
     sde.set_model(_model)
     fn = sde.reverse_sde if mode == "sde" else sde.reverse_posterior
     out = fn(xt.cuda(), noise_tape=tape.cuda())
-    assert max_abs(out.cpu().numpy(), ref.numpy()) < 1e-4
+    # the stand-in score model is expansive (|x| grows to O(50)): fp32 chain error is judged relative to the range
+    assert max_abs(out.cpu().numpy(), ref.numpy()) < 1e-5 * max(1.0, float(ref.abs().max()))
     # the caller's state is not modified; a second run is bit-identical
     out2 = fn(xt.cuda(), noise_tape=tape.cuda())
     assert torch.equal(out, out2)
