@@ -172,6 +172,26 @@ int uwir_sde_posterior_step(const float* x, const float* mu, const float* noise,
                             size_t numel, float sigma_bar, float expA, float term1, float term2, float std,
                             uwir_stream_t stream);
 
+/* ---- per-token LayerNorm: open_clip LayerNorm (L/open_clip/transformer.py:22-28, used at :441,:208,:215,:475)
+ * and the gain-only channel LayerNorm of the IR-SDE UNet (U/models/modules/module_util.py:77-86) ----------------
+ * y[m,:] = LN(x[m,:] + add[m % add_period,:]) * gamma + beta over the C channels of row m (biased variance, eps
+ * inside the sqrt).  add may be NULL (else [add_period, add_ld]: the ViT's positional + class embedding,
+ * transformer.py:527-536); beta may be NULL.  x fp32 (row stride ldx), y fp32 or bf16 (row stride ldy). C % 4 == 0. */
+int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
+                 const float* gamma, const float* beta, float eps, void* y, int y_dtype, size_t ldy,
+                 uwir_stream_t stream);
+
+/* ---- ViT patch embedding gather: im2col of Conv2d(3,width,k=P,stride=P), L/open_clip/transformer.py:409,522 ------
+ * img NCHW fp32 [B,Cin,H,W] -> out rows [B*(G+1), Cin*P*P] (G = (H/P)*(W/P) patches, k = (c*P+ky)*P+kx, i.e. the
+ * layout of conv1.weight.reshape(width,-1)); row 0 of each image is zero (class-token slot, :527-530). */
+int uwir_patchify(const float* img_nchw, int B, int Cin, int H, int W, int P, void* out, int out_dtype, size_t ldo,
+                  uwir_stream_t stream);
+
+/* ---- `x += control.pop()` with materialised hiddens (L/open_clip/transformer.py:367-368) and other plain
+ * residual adds: out[m,:] = a[m,:] + b[m,:], fp32 row matrices, out may alias a or b.  C % 4 == 0. */
+int uwir_add_rows(const float* a, size_t lda, const float* b, size_t ldb, float* out, size_t ldo, int M, int C,
+                  uwir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,24 @@ STUDENT_CASES = {
                    mask_hw=(7, 7), wseed=2, xseed=5, taps=_TAPS),
 }
 
+DACLIP_CASES = {
+    # reduced width: every stage exercised, outputs + all hiddens stored in full
+    "small": dict(image_size=64, patch_size=32, width=128, layers=3, heads=2, output_dim=64, batch=3, wseed=3, xseed=21,
+                  store_hiddens=True),
+    # 7x7 grid (50 tokens like ViT-B/32) at reduced width, more layers than control pops in a symmetric position
+    "grid7": dict(image_size=224, patch_size=32, width=192, layers=4, heads=3, output_dim=512, batch=2, wseed=4, xseed=22,
+                  store_hiddens=True),
+    # the production tower: daclip_ViT-B-32.json (width 768, 12 layers, 12 heads), outputs only
+    "vitb32": dict(image_size=224, patch_size=32, width=768, layers=12, heads=12, output_dim=512, batch=1, wseed=5,
+                   xseed=23, store_hiddens=False),
+}
+
+
+def daclip_image(cfg: dict):
+    import torch
+    g = torch.Generator().manual_seed(cfg["xseed"])
+    return torch.randn(cfg["batch"], 3, cfg["image_size"], cfg["image_size"], generator=g)
+
 
 def compress(t, limit: int = 4096) -> np.ndarray:
     """Full tensor when small, else an evenly strided sample plus [mean, mean|.|] appended."""

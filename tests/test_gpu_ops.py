@@ -375,3 +375,41 @@ def test_sde_steps(ops):
         xc = x.cuda()
         ops.sde_posterior_step(xc, mu.cuda(), nz.cuda(), eps.cuda(), xc, sbar, expA, t1, t2, sd)  # in place
         assert err(xc, refp) < 1e-5
+
+
+@pytest.mark.parametrize("odt", ["fp32", "bf16"])
+def test_ln_rows(ops, odt):
+    g = torch.Generator().manual_seed(13)
+    for (m, c, period) in ((7, 768, 0), (100, 64, 50), (5, 1028, 5), (3, 4, 0)):
+        x = torch.randn(m, c + 4, generator=g) * 2 + 1
+        gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        add = torch.randn(period, c, generator=g) if period else None
+        xin = x[:, :c].double() + (add.double().repeat(m // period, 1) if period else 0)
+        ref = F.layer_norm(xin, (c,), gamma.double(), beta.double(), 1e-5)
+        y = torch.full((m, c + 8), 3.0, device="cuda", dtype=_wdt(odt))
+        ops.ln_rows(x.cuda()[:, :c], gamma.cuda(), beta.cuda(), y[:, :c], 1e-5, add=None if add is None else add.cuda(),
+                    add_period=period)
+        assert err(y[:, :c], ref) < (1e-5 if odt == "fp32" else 4e-2)
+        assert float(y[:, c:].float().min()) == 3.0
+        if odt == "fp32":  # gain-only variant (IR-SDE UNet LayerNorm) and in-place
+            xc = x.cuda()
+            ops.ln_rows(xc[:, :c], gamma.cuda(), None, xc[:, :c], 1e-5)
+            assert err(xc[:, :c], F.layer_norm(x[:, :c].double(), (c,), gamma.double(), None, 1e-5)) < 1e-5
+
+
+def test_patchify_and_add_rows(ops):
+    g = torch.Generator().manual_seed(14)
+    img = torch.randn(2, 3, 64, 96, generator=g)
+    P = 32
+    ref = F.unfold(img, kernel_size=P, stride=P).permute(0, 2, 1)  # (B, G, 3*P*P), k = (c, ky, kx)
+    out = torch.full((2 * 7, 3 * P * P), 9.0, device="cuda")
+    ops.patchify(img.cuda(), P, out)
+    got = out.reshape(2, 7, -1).cpu()
+    assert float(got[:, 0].abs().max()) == 0.0 and torch.equal(got[:, 1:], ref)
+    outb = torch.empty(2 * 7, 3 * P * P, device="cuda", dtype=torch.bfloat16)
+    ops.patchify(img.cuda(), P, outb)
+    assert torch.equal(outb.reshape(2, 7, -1)[:, 1:].cpu(), ref.to(torch.bfloat16))
+    a, b = torch.randn(9, 24, generator=g).cuda(), torch.randn(9, 24, generator=g).cuda()
+    exp = a[:, :20] + b[:, 4:]
+    ops.add_rows(a[:, :20], b[:, 4:], a[:, :20])
+    assert torch.equal(a[:, :20], exp)

@@ -58,6 +58,9 @@ _SIGS = {
     "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
+    "uwir_ln_rows": (ci, [vp, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, ci, sz, vp]),
+    "uwir_add_rows": (ci, [vp, sz, vp, sz, vp, sz, ci, ci, vp]),
+    "uwir_patchify": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, sz, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

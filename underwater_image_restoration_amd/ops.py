@@ -228,3 +228,39 @@ def sde_posterior_step(x, mu, noise, eps, x_out, sigma_bar: float, expA: float, 
     lib = _lib.load()
     _lib.check(lib.uwir_sde_posterior_step(_p(x), _p(mu), _p(noise), _p(eps), _p(x_out), x.numel(), sigma_bar, expA,
                                            term1, term2, std, _stream()), "sde_posterior_step")
+
+
+def gemm(A: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor, **kw) -> None:
+    """Plain row-matrix GEMM out = epilogue(A @ Wt^T) through the conv entry point (1 x M "image")."""
+    conv_gemm(A, Wt, out, B=1, H=1, W=A.shape[0], C_=Wt.shape[1], N=Wt.shape[0], **kw)
+
+
+def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, add=None, add_period: int = 0) -> None:
+    """y[m] = LayerNorm_C(x[m] + add[m % add_period]) * gamma + beta; x fp32 [M, C] view, y fp32/bf16."""
+    _f32(x, gamma, beta, add)
+    lib = _lib.load()
+    M, C_ = x.shape
+    if y.shape[0] != M or y.shape[1] != C_ or gamma.numel() != C_:
+        raise ValueError("ln_rows: shape mismatch")
+    if add is not None and (add.shape[0] != add_period or add.shape[1] != C_):
+        raise ValueError("ln_rows: add table must be [add_period, C]")
+    _lib.check(lib.uwir_ln_rows(_p(x), _ld(x), M, C_, _p(add), add_period, 0 if add is None else _ld(add), _p(gamma),
+                                _p(beta), eps, _p(y), _dt(y), _ld(y), _stream()), "ln_rows")
+
+
+def patchify(img: torch.Tensor, P: int, out: torch.Tensor) -> None:
+    _f32(img)
+    lib = _lib.load()
+    if img.dim() != 4 or not img.is_contiguous():
+        raise ValueError("patchify: image must be a contiguous NCHW tensor")
+    B, Cin, H, W = img.shape
+    _lib.check(lib.uwir_patchify(_p(img), B, Cin, H, W, P, _p(out), _dt(out), _ld(out), _stream()), "patchify")
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
+    _f32(a, b, out)
+    lib = _lib.load()
+    M, C_ = a.shape
+    if b.shape != a.shape or out.shape != a.shape:
+        raise ValueError("add_rows: shape mismatch")
+    _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C_, _stream()), "add_rows")

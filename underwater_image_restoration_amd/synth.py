@@ -104,6 +104,50 @@ def student_param_shapes(in_channels: int = 3, out_channels: int = 3, base_chann
     return out
 
 
+def _vit_tower_shapes(p: str, tp: str, image_size: int, patch: int, width: int, layers: int, out_dim: int,
+                      out: "OrderedDict[str, Tuple[int, ...]]") -> None:
+    """One open_clip ``VisionTransformer`` (L/open_clip/transformer.py:376-442); ``tp`` = prefix of its resblocks."""
+    grid = image_size // patch
+    out[p + "class_embedding"] = (width,)
+    out[p + "positional_embedding"] = (grid * grid + 1, width)
+    out[p + "proj"] = (width, out_dim)
+    out[p + "conv1.weight"] = (width, 3, patch, patch)
+    out[p + "ln_pre.weight"] = (width,)
+    out[p + "ln_pre.bias"] = (width,)
+    for i in range(layers):
+        r = f"{tp}resblocks.{i}."
+        out[r + "ln_1.weight"] = (width,)
+        out[r + "ln_1.bias"] = (width,)
+        out[r + "attn.in_proj_weight"] = (3 * width, width)
+        out[r + "attn.in_proj_bias"] = (3 * width,)
+        out[r + "attn.out_proj.weight"] = (width, width)
+        out[r + "attn.out_proj.bias"] = (width,)
+        out[r + "ln_2.weight"] = (width,)
+        out[r + "ln_2.bias"] = (width,)
+        out[r + "mlp.c_fc.weight"] = (4 * width, width)
+        out[r + "mlp.c_fc.bias"] = (4 * width,)
+        out[r + "mlp.c_proj.weight"] = (width, 4 * width)
+        out[r + "mlp.c_proj.bias"] = (width,)
+    out[p + "ln_post.weight"] = (width,)
+    out[p + "ln_post.bias"] = (width,)
+
+
+def daclip_vision_param_shapes(image_size: int = 224, patch_size: int = 32, width: int = 768, layers: int = 12,
+                               output_dim: int = 512) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Weight ABI of the vision side of ``DaCLIP`` (L/open_clip/daclip_model.py:17-24): ``visual.*`` is the CLIP
+    ViT, ``visual_control.*`` its copy whose transformer is wrapped in ``ControlTransformer``
+    (L/open_clip/transformer.py:288-306: ``transformer.transformer.resblocks.*`` + ``transformer.zero_modules.*``).
+    Defaults = model_configs/daclip_ViT-B-32.json."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    _vit_tower_shapes("visual.", "visual.transformer.", image_size, patch_size, width, layers, output_dim, out)
+    _vit_tower_shapes("visual_control.", "visual_control.transformer.transformer.", image_size, patch_size, width, layers,
+                      output_dim, out)
+    for i in range(layers):
+        out[f"visual_control.transformer.zero_modules.{i}.weight"] = (width, width)
+        out[f"visual_control.transformer.zero_modules.{i}.bias"] = (width,)
+    return out
+
+
 def _key_seed(seed: int, key: str) -> int:
     return int.from_bytes(hashlib.sha256(f"{seed}:{key}".encode()).digest()[:6], "little")
 
@@ -118,11 +162,14 @@ def synth_state_dict(shapes: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0,
     sd: Dict[str, torch.Tensor] = {}
     for key, shape in shapes.items():
         g = torch.Generator().manual_seed(_key_seed(seed, key))
-        is_norm = ".norm.weight" in key or key == "final_norm.weight" or key.endswith(".g")
+        is_norm = ".norm.weight" in key or key == "final_norm.weight" or key.endswith(".g") or \
+            (".ln_" in key and key.endswith(".weight"))
         if is_norm:
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float64)
         elif key.endswith("bias"):
             t = 0.1 * (2 * torch.rand(shape, generator=g, dtype=torch.float64) - 1)
+        elif key.endswith(("class_embedding", "positional_embedding", ".proj")) and key.startswith("visual"):
+            t = shape[-1 if key.endswith("embedding") else 0] ** -0.5 * torch.randn(shape, generator=g, dtype=torch.float64)
         else:
             fan_in = 1
             for s in shape[1:]:
