@@ -3,7 +3,9 @@
     python bench.py [--gpus N --steps K --warmup W] [--precision bf16|fp32] [--batch 16 --size 256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one forward of the hot path over one batch of synthetic images already resident in HBM.
+A "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+DA-CLIP ViT-B/32 encode_image(control=True) on the (B,3,224,224) CLIP view -> z_d = degra_features (B,512)
+-> student NAFNetWFIGate forward on the (B,3,256,256) images conditioned on z_d and (B,10,7,7) masks.
 N=1 workload = BASELINE.json configs[1]: batch 16 at 256x256, bf16 MFMA compute.
 N>1: images are independent, so every rank runs its own batch (weak scaling, no data-path collective);
 RCCL is used only for the barrier and the MAX-over-ranks of the step time.
@@ -25,24 +27,32 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
 
 
+DACLIP_GF_PER_IMAGE = 18.2e9  # both ViT-B/32 towers, SURVEY.md section 6
+
+
 def student_flops(batch: int, size: int) -> float:
-    """462*(S/256)^2 + 1401*(S/256)^4 GF per image."""
+    """462*(S/256)^2 + 1401*(S/256)^4 GF per image (+ 18.2 GF for the DA-CLIP towers)."""
     r = size / 256.0
-    return batch * (462e9 * r * r + 1401e9 * r ** 4)
+    return batch * (462e9 * r * r + 1401e9 * r ** 4 + DACLIP_GF_PER_IMAGE)
 
 
-def cpu_baseline(mk, sd, size: int, threads: int):
-    """The oracle (CPU restatement of the reference, oracle/student_ref.py) timed on the host cores."""
+def cpu_baseline(mk, sd, clip_sd, size: int, threads: int):
+    """The oracle (CPU restatement of the reference: oracle/daclip_ref.py + oracle/student_ref.py) timed on the
+    host cores on a bounded sample of the same workload (one image)."""
+    from oracle import daclip_ref as DR
     from oracle import student_ref as R
     from underwater_image_restoration_amd.synth import synth_student_inputs
     torch.set_num_threads(threads)
-    x, z, m = synth_student_inputs(1, size, size, mk["cond_dim"], mk["num_masks"], mask_hw=(7, 7), seed=1234)
+    x, _, m = synth_student_inputs(1, size, size, mk["cond_dim"], mk["num_masks"], mask_hw=(7, 7), seed=1234)
+    clip_in = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(7))
     t0 = time.time()
     with torch.no_grad():
+        _, z = DR.encode_image(clip_sd, clip_in, 12, control=True)
         R.student_forward(sd, x, z, m, blocks_per_level=mk["blocks_per_level"])
     dt = time.time() - t0
     return {"value": round(size * size / 1e6 / dt, 6), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": f"1 image {size}x{size} fp32 (oracle/student_ref.py, torch CPU), {dt:.1f} s"}
+            "sample": f"1 image {size}x{size} fp32: DA-CLIP encode + student forward "
+                      f"(oracle/daclip_ref.py + oracle/student_ref.py, torch CPU, {threads} threads), {dt:.1f} s"}
 
 
 def main() -> None:
@@ -68,18 +78,26 @@ def main() -> None:
 
     from underwater_image_restoration_amd import ops
     from underwater_image_restoration_amd.student import NAFNetWFIGate
-    from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
+    from underwater_image_restoration_amd.daclip import DaCLIPVision
+    from underwater_image_restoration_amd.synth import (daclip_vision_param_shapes, student_param_shapes,
+                                                        synth_state_dict, synth_student_inputs)
 
     mk = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
     sd = synth_state_dict(student_param_shapes(**mk), seed=0)
     model = NAFNetWFIGate(**mk, precision=args.precision)
     model.load_state_dict(sd)
     model = model.cuda().eval()
-    x, z, m = synth_student_inputs(args.batch, args.size, args.size, 512, 10, mask_hw=(7, 7), seed=1234 + rank)
-    x, z, m = x.cuda(), z.cuda(), m.cuda()
+    clip_sd = synth_state_dict(daclip_vision_param_shapes(), seed=1)
+    clip = DaCLIPVision(precision=args.precision)
+    clip.load_state_dict(clip_sd)
+    clip = clip.cuda().eval()
+    x, _, m = synth_student_inputs(args.batch, args.size, args.size, 512, 10, mask_hw=(7, 7), seed=1234 + rank)
+    clip_in = torch.randn(args.batch, 3, 224, 224, generator=torch.Generator().manual_seed(7 + rank))
+    x, m, clip_in = x.cuda(), m.cuda(), clip_in.cuda()
 
     def step():
-        return model(x, z, m)
+        _, z_d = clip.encode_image(clip_in, control=True)   # U/test.py:114-117: degra_features condition the net
+        return model(x, z_d, m)
 
     for _ in range(args.warmup):
         step()
@@ -96,7 +114,6 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.event_timing(False) if False else None
     timings = ops.collect_event_timings()
     ops.event_timing(False)
     if dist is not None:
@@ -121,15 +138,15 @@ def main() -> None:
         cpu = None
         if args.cpu_baseline != "skip" and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            cpu = cpu_baseline(mk, sd, args.cpu_size, threads)
+            cpu = cpu_baseline(mk, sd, clip_sd, args.cpu_size, threads)
         line = {
-            "metric": "restored megapixels/sec (whole node), student forward", "value": round(mp / elapsed, 4),
+            "metric": "restored megapixels/sec (whole node)", "value": round(mp / elapsed, 4),
             "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"student NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
-                                   f"{args.precision} MFMA compute (BASELINE configs[1]); z_d synthetic N(0,1) 512-d "
-                                   "(DA-CLIP ViT-B/32 tower not on this path yet), masks (10,7,7)",
+            "config": {"workload": f"BASELINE configs[1]: DA-CLIP ViT-B/32 encode_image(control=True) -> z_d (512) -> student "
+                                   f"NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
+                                   f"{args.precision} MFMA compute, masks (10,7,7)",
                        "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
                        "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
                        "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
