@@ -37,6 +37,31 @@ def daclip_image(cfg: dict):
     g = torch.Generator().manual_seed(cfg["xseed"])
     return torch.randn(cfg["batch"], 3, cfg["image_size"], cfg["image_size"], generator=g)
 
+UNET_CASES = {
+    # LinearAttention only (depth 2), odd sizes -> reflect pad + crop, integer time
+    "lin": dict(nf=32, ch_mult=[1, 2], degra=True, image=False, batch=2, H=30, W=36, times=[50], wseed=6, xseed=31),
+    # the test.yml topology at half width: SpatialTransformer at level 3 + mid, both contexts, two times
+    "full4": dict(nf=32, ch_mult=[1, 2, 4, 8], degra=True, image=True, batch=2, H=64, W=48, times=[100, 1], wseed=7,
+                  xseed=32),
+    # production width (U/options/test.yml:30-39), float time like t * sample_scale
+    "prod": dict(nf=64, ch_mult=[1, 2, 4, 8], degra=True, image=True, batch=1, H=32, W=32, times=[37.0], wseed=8,
+                 xseed=33),
+    # no conditioning branches at all (context unused), ch_mult with a repeated last width
+    "noctx": dict(nf=32, ch_mult=[1, 2, 4, 4], degra=False, image=False, batch=1, H=32, W=32, times=[7], wseed=9,
+                  xseed=34),
+}
+
+
+def unet_inputs(cfg: dict):
+    """mu = x ~ U[0,1), xt = mu + randn * 50/255, contexts ~ N(0,1)."""
+    import torch
+    g = torch.Generator().manual_seed(cfg["xseed"])
+    mu = torch.rand(cfg["batch"], 3, cfg["H"], cfg["W"], generator=g)
+    xt = mu + torch.randn(mu.shape, generator=g) * (50 / 255)
+    text = torch.randn(cfg["batch"], 512, generator=g)
+    image = torch.randn(cfg["batch"], 512, generator=g)
+    return xt, mu, (text if cfg["degra"] else None), (image if cfg["image"] else None)
+
 
 def compress(t, limit: int = 4096) -> np.ndarray:
     """Full tensor when small, else an evenly strided sample plus [mean, mean|.|] appended."""

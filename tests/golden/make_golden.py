@@ -23,8 +23,9 @@ sys.path.insert(0, "/root/reference")
 
 from underwater_image_restoration_amd.synth import (student_param_shapes, synth_state_dict,  # noqa: E402
                                                     synth_student_inputs)
-from underwater_image_restoration_amd.synth import daclip_vision_param_shapes  # noqa: E402
-from tests.golden.cases import DACLIP_CASES, STUDENT_CASES, compress, daclip_image  # noqa: E402
+from underwater_image_restoration_amd.synth import daclip_vision_param_shapes, unet_param_shapes  # noqa: E402
+from tests.golden.cases import (DACLIP_CASES, STUDENT_CASES, UNET_CASES, compress, daclip_image,  # noqa: E402
+                                unet_inputs)
 
 
 def student_case(name: str, cfg: dict) -> None:
@@ -203,10 +204,43 @@ def daclip_case(name: str, cfg: dict) -> None:
     print("daclip", name, "image |max|", float(np.abs(store["image"]).max()), "degra |max|", float(np.abs(store["degra"]).max()))
 
 
+def unet_case(name: str, cfg: dict) -> None:
+    """ConditionalUNet imported from the reference's daclip-sde app (needs only torch + einops)."""
+    sys.path.insert(0, "/root/reference/legacy/third_party/universal-image-restoration/config/daclip-sde")
+    from models.modules import ConditionalUNet
+    model = ConditionalUNet(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"]).eval()
+    shapes = unet_param_shapes(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"])
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == dict(shapes), "UNet state_dict mismatch"
+    model.load_state_dict(synth_state_dict(shapes, seed=cfg["wseed"]), strict=True)
+    xt, mu, text, image = unet_inputs(cfg)
+    taps = {}
+    hooks = {"mid": model.mid_block2}
+    for i in range(len(cfg["ch_mult"])):
+        hooks[f"down{i}"] = model.downs[i][2]
+        hooks[f"up{i}"] = model.ups[i][2]
+    for tag, mod in hooks.items():
+        mod.register_forward_hook(lambda m, inp, out, tag=tag: taps.__setitem__(tag, out.detach()))
+    store = {}
+    with torch.no_grad():
+        for ti, t in enumerate(cfg["times"]):
+            out = model(xt, mu, t, text_context=text, image_context=image)
+            store[f"out{ti}"] = out.numpy()
+            if ti == 0:
+                for k, v in taps.items():
+                    store["tap:" + k] = compress(v)
+        m64 = model.double()
+        d = lambda z: None if z is None else z.double()  # noqa: E731
+        for ti, t in enumerate(cfg["times"]):
+            t64 = torch.tensor([float(t)], dtype=torch.float64)  # an int/float time would give an fp32 embedding
+            store[f"out{ti}_f64"] = m64(xt.double(), mu.double(), t64, text_context=d(text), image_context=d(image)).numpy()
+    np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **store)
+    print("unet", name, "out |max|", float(np.abs(store["out0"]).max()), "fp32-vs-fp64", float(np.abs(store["out0"] - store["out0_f64"]).max()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip"}
+    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet"}
     if "dwt" in which:
         dwt_case()
     if "student" in which:
@@ -217,3 +251,6 @@ if __name__ == "__main__":
     if "daclip" in which:
         for name, cfg in DACLIP_CASES.items():
             daclip_case(name, cfg)
+    if "unet" in which:
+        for name, cfg in UNET_CASES.items():
+            unet_case(name, cfg)

@@ -1,0 +1,49 @@
+"""CPU: pin oracle/unet_ref.py against golden vectors produced by the reference's own ConditionalUNet
+(tests/golden/make_golden.py::unet_case)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref as U
+from tests.golden.cases import UNET_CASES, compress, unet_inputs
+from tests.helpers import max_abs
+from underwater_image_restoration_amd.synth import synth_state_dict, unet_param_shapes
+
+
+def unet_case_setup(name, golden_dir):
+    cfg = UNET_CASES[name]
+    sd = synth_state_dict(unet_param_shapes(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"]), seed=cfg["wseed"])
+    return cfg, sd, unet_inputs(cfg), np.load(os.path.join(golden_dir, f"unet_{name}.npz"))
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_unet_oracle_matches_reference(golden_dir, name):
+    cfg, sd, (xt, mu, text, image), g = unet_case_setup(name, golden_dir)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    d = lambda z: None if z is None else z.double()  # noqa: E731
+    for ti, t in enumerate(cfg["times"]):
+        taps = {}
+        with torch.no_grad():
+            out = U.unet_forward(sd, xt, mu, t, text, image, taps=taps)
+            o64 = U.unet_forward(sd64, xt.double(), mu.double(), torch.tensor([float(t)], dtype=torch.float64), d(text), d(image))
+        assert out.shape == xt.shape
+        assert max_abs(out.numpy(), g[f"out{ti}"]) < 2e-5, (name, t)           # fp32: same math, other summation order
+        assert max_abs(o64.numpy(), g[f"out{ti}_f64"]) < 1e-10, (name, t)     # fp64 (eps 1e-3 branch): math pinned
+        if ti == 0:
+            for k in g.files:
+                if k.startswith("tap:"):
+                    assert max_abs(compress(taps[k[4:]]), g[k]) < 5e-5, k
+
+
+def test_force_eps_gives_high_precision_fp32_function(golden_dir):
+    cfg, sd, (xt, mu, text, image), g = unet_case_setup("lin", golden_dir)
+    U.FORCE_EPS = 1e-5
+    try:
+        with torch.no_grad():
+            o64 = U.unet_forward({k: v.double() for k, v in sd.items()}, xt.double(), mu.double(),
+                                 torch.tensor([50.0], dtype=torch.float64), text.double(), None)
+    finally:
+        U.FORCE_EPS = None
+    assert max_abs(o64.numpy(), g["out0"]) < 2e-5

@@ -9,6 +9,7 @@ equal to the reference's own ``state_dict()`` listing.
 from __future__ import annotations
 
 import hashlib
+import re
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -148,6 +149,87 @@ def daclip_vision_param_shapes(image_size: int = 224, patch_size: int = 32, widt
     return out
 
 
+def unet_param_shapes(in_nc: int = 3, out_nc: int = 3, nf: int = 64, ch_mult=(1, 2, 4, 8), context_dim: int = 512,
+                      use_degra_context: bool = True, use_image_context: bool = True
+                      ) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Weight ABI of the IR-SDE ``ConditionalUNet`` (U/models/modules/DenoisingUNet_arch.py:22-109 and the
+    constructors in module_util.py / attention.py it calls).  Defaults = U/options/test.yml:30-39."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    td = nf * 4
+    ctx = context_dim if context_dim is not None else -1
+    if ctx > 0 and use_degra_context:
+        out["prompt"] = (1, td)
+    out["init_conv.weight"] = (nf, 2 * in_nc, 7, 7)
+    out["time_mlp.1.weight"], out["time_mlp.1.bias"] = (td, nf), (td,)
+    out["time_mlp.3.weight"], out["time_mlp.3.bias"] = (td, td), (td,)
+    if ctx > 0 and use_degra_context:
+        out["text_mlp.0.weight"], out["text_mlp.0.bias"] = (td, ctx), (td,)
+        out["text_mlp.2.weight"], out["text_mlp.2.bias"] = (td, td), (td,)
+        out["prompt_mlp.weight"], out["prompt_mlp.bias"] = (td, td), (td,)
+
+    def resblock(p: str, din: int, dout: int) -> None:
+        out[p + "mlp.1.weight"], out[p + "mlp.1.bias"] = (2 * dout, td), (2 * dout,)
+        out[p + "block1.proj.weight"] = (dout, din, 3, 3)
+        out[p + "block2.proj.weight"] = (dout, dout, 3, 3)
+        if din != dout:
+            out[p + "res_conv.weight"] = (dout, din, 1, 1)
+
+    def attn(p: str, dim: int, spatial: bool) -> None:
+        if not spatial:                                   # Residual(PreNorm(dim, LinearAttention(dim)))
+            out[p + "fn.fn.to_qkv.weight"] = (384, dim, 1, 1)
+            out[p + "fn.fn.to_out.0.weight"], out[p + "fn.fn.to_out.0.bias"] = (dim, 128, 1, 1), (dim,)
+            out[p + "fn.fn.to_out.1.g"] = (1, dim, 1, 1)
+        else:                                             # Residual(PreNorm(dim, SpatialTransformer(dim, dim//32, 32)))
+            f = p + "fn.fn."
+            out[f + "norm.weight"], out[f + "norm.bias"] = (dim,), (dim,)
+            out[f + "proj_in.weight"], out[f + "proj_in.bias"] = (dim, dim, 1, 1), (dim,)
+            t = f + "transformer_blocks.0."
+            for nm in ("to_q", "to_k", "to_v"):
+                out[t + f"attn1.{nm}.weight"] = (dim, dim)
+            out[t + "attn1.to_out.0.weight"], out[t + "attn1.to_out.0.bias"] = (dim, dim), (dim,)
+            out[t + "ff.net.0.proj.weight"], out[t + "ff.net.0.proj.bias"] = (8 * dim, dim), (8 * dim,)
+            out[t + "ff.net.2.weight"], out[t + "ff.net.2.bias"] = (dim, 4 * dim), (dim,)
+            out[t + "attn2.to_q.weight"] = (dim, dim)
+            out[t + "attn2.to_k.weight"], out[t + "attn2.to_v.weight"] = (dim, ctx), (dim, ctx)
+            out[t + "attn2.to_out.0.weight"], out[t + "attn2.to_out.0.bias"] = (dim, dim), (dim,)
+            for nm in ("norm1", "norm2", "norm3"):
+                out[t + nm + ".weight"], out[t + nm + ".bias"] = (dim,), (dim,)
+            out[f + "proj_out.weight"], out[f + "proj_out.bias"] = (dim, dim, 1, 1), (dim,)
+        out[p + "fn.norm.g"] = (1, dim, 1, 1)
+
+    depth = len(ch_mult)
+    mult = [1] + list(ch_mult)
+    img_ctx = use_image_context and ctx > 0
+    for i in range(depth):
+        din, dout = nf * mult[i], nf * mult[i + 1]
+        p = f"downs.{i}."
+        resblock(p + "0.", din, din)
+        resblock(p + "1.", din, din)
+        attn(p + "2.", din, img_ctx and i >= 3)
+        if i != depth - 1:
+            out[p + "3.weight"], out[p + "3.bias"] = (dout, din, 4, 4), (dout,)
+        else:
+            out[p + "3.weight"] = (dout, din, 3, 3)
+    for j in range(depth):                                # ups.insert(0, ...): ups[j] belongs to level depth-1-j
+        i = depth - 1 - j
+        din, dout = nf * mult[i], nf * mult[i + 1]
+        p = f"ups.{j}."
+        resblock(p + "0.", dout + din, dout)
+        resblock(p + "1.", dout + din, dout)
+        attn(p + "2.", dout, img_ctx and i >= 3)
+        if i != 0:
+            out[p + "3.1.weight"], out[p + "3.1.bias"] = (din, dout, 3, 3), (din,)
+        else:
+            out[p + "3.weight"] = (din, dout, 3, 3)
+    mid = nf * mult[-1]
+    resblock("mid_block1.", mid, mid)
+    attn("mid_attn.", mid, img_ctx)
+    resblock("mid_block2.", mid, mid)
+    resblock("final_res_block.", 2 * nf, nf)
+    out["final_conv.weight"], out["final_conv.bias"] = (out_nc, nf, 3, 3), (out_nc,)
+    return out
+
+
 def _key_seed(seed: int, key: str) -> int:
     return int.from_bytes(hashlib.sha256(f"{seed}:{key}".encode()).digest()[:6], "little")
 
@@ -163,7 +245,7 @@ def synth_state_dict(shapes: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0,
     for key, shape in shapes.items():
         g = torch.Generator().manual_seed(_key_seed(seed, key))
         is_norm = ".norm.weight" in key or key == "final_norm.weight" or key.endswith(".g") or \
-            (".ln_" in key and key.endswith(".weight"))
+            (".ln_" in key and key.endswith(".weight")) or re.search(r"norm\d\.weight$", key) is not None
         if is_norm:
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float64)
         elif key.endswith("bias"):
