@@ -92,7 +92,7 @@ typedef struct uwir_gemm_args {
     int w_dtype, N;
     const float* bias;       /* [N] or NULL */
     const float* batch_bias; /* [B, N] or NULL (per-sample bias, e.g. folded cond_proj of the gate) */
-    int act;                 /* uwir_act, applied to acc + bias + batch_bias */
+    int act;                 /* uwir_act, applied to (acc + bias) * batch_scale + batch_bias */
     const float* res;        /* optional fp32 residual [M, ldr] added after act */
     int ldr;
     const float* res_scale;  /* optional [B, N]: residual enters as res*res_scale + res_shift */
@@ -109,6 +109,12 @@ typedef struct uwir_gemm_args {
     int compute;             /* UWIR_F32: exact-fp32 MFMA; UWIR_BF16: bf16 MFMA, fp32 accumulate */
     const float* col_scale;  /* optional [N]: value *= col_scale[n] after act, before the residual (used to hand
                                 attention a Q that already carries scale*log2(e), rounded to bf16 only once) */
+    const float* batch_scale; /* optional [B, N]: (acc + bias) *= batch_scale[b,n] BEFORE batch_bias and act -- the
+                                 IR-SDE ResBlock's x*(scale+1)+shift (U/models/modules/module_util.py:121-128) */
+    int ups;                  /* 1: A is read through a nearest-neighbour 2x upsample (nn.Upsample(scale_factor=2) +
+                                 Conv2d, module_util.py:100-104); H, W stay the SOURCE size, OH/OW refer to 2H x 2W */
+    int batch_ld;             /* row stride of batch_bias / batch_scale (0 = N): lets one [B, total] matrix hold the
+                                 per-sample vectors of many layers */
 } uwir_gemm_args;
 int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);
 
@@ -174,12 +180,14 @@ int uwir_sde_posterior_step(const float* x, const float* mu, const float* noise,
 
 /* ---- per-token LayerNorm: open_clip LayerNorm (L/open_clip/transformer.py:22-28, used at :441,:208,:215,:475)
  * and the gain-only channel LayerNorm of the IR-SDE UNet (U/models/modules/module_util.py:77-86) ----------------
- * y[m,:] = LN(x[m,:] + add[m % add_period,:]) * gamma + beta over the C channels of row m (biased variance, eps
- * inside the sqrt).  add may be NULL (else [add_period, add_ld]: the ViT's positional + class embedding,
- * transformer.py:527-536); beta may be NULL.  x fp32 (row stride ldx), y fp32 or bf16 (row stride ldy). C % 4 == 0. */
+ * y[m,:] = LN(x[m,:] + add[m % add_period,:]) * gamma + beta (+ res[m,:]) over the C channels of row m (biased
+ * variance, eps inside the sqrt).  add may be NULL (else [add_period, add_ld]: the ViT's positional + class
+ * embedding, transformer.py:527-536); beta may be NULL; res (fp32, row stride ldr) may be NULL, else it is the
+ * skip of Residual(PreNorm(..)) added after the norm (module_util.py:27-33).  x fp32 (row stride ldx), y fp32 or
+ * bf16 (row stride ldy), y may alias x or res when fp32.  C % 4 == 0. */
 int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
-                 const float* gamma, const float* beta, float eps, void* y, int y_dtype, size_t ldy,
-                 uwir_stream_t stream);
+                 const float* gamma, const float* beta, float eps, const float* res, size_t ldr, void* y, int y_dtype,
+                 size_t ldy, uwir_stream_t stream);
 
 /* ---- ViT patch embedding gather: im2col of Conv2d(3,width,k=P,stride=P), L/open_clip/transformer.py:409,522 ------
  * img NCHW fp32 [B,Cin,H,W] -> out rows [B*(G+1), Cin*P*P] (G = (H/P)*(W/P) patches, k = (c*P+ky)*P+kx, i.e. the
@@ -191,6 +199,43 @@ int uwir_patchify(const float* img_nchw, int B, int Cin, int H, int W, int P, vo
  * residual adds: out[m,:] = a[m,:] + b[m,:], fp32 row matrices, out may alias a or b.  C % 4 == 0. */
 int uwir_add_rows(const float* a, size_t lda, const float* b, size_t ldb, float* out, size_t ldo, int M, int C,
                   uwir_stream_t stream);
+
+/* ======================= IR-SDE score network (U = L/config/daclip-sde/models/modules/) ======================= */
+
+/* ---- U/DenoisingUNet_arch.py:123-127 + check_image_size :111-116 -------------------------------------------------
+ * out NHWC fp32 [B,Hp,Wp,Cp] = cat([xt - cond, cond]) reflect-padded right/bottom to Hp x Wp, channels zero-filled
+ * from 2*Cin up to Cp (so the 7x7 stem conv runs through uwir_conv_gemm).  xt, cond NCHW fp32 [B,Cin,H,W]. */
+int uwir_unet_input(const float* xt_nchw, const float* cond_nchw, int B, int Cin, int H, int W, int Hp, int Wp, int Cp,
+                    float* out, uwir_stream_t stream);
+
+/* ---- nn.GroupNorm(32, C, eps=1e-6) of SpatialTransformer (U/attention.py:76-77,236,254) as a folded affine ------
+ * x [B,n,C] fp32 -> a[b,c], s[b,c] with GroupNorm(x) == a*x + s, consumed by the next GEMM's a_scale/a_shift.
+ * workspace >= uwir_ln2d_workspace_bytes(B,n,C). */
+int uwir_groupnorm_affine(const float* x, int ldx, int B, int n, int C, int groups, float eps, const float* gamma,
+                          const float* beta, float* a_out, float* s_out, void* workspace, size_t workspace_bytes,
+                          uwir_stream_t stream);
+
+/* ---- LinearAttention core, U/module_util.py:170-183 ---------------------------------------------------------------
+ * qkv [B*n, ld] = [q | k | v], each heads*32 wide (head-major); out[n, h*32+e] =
+ * sum_d ( sum_m softmax_m(k)[m,d] v[m,e] / n ) * softmax_d(q[n,h,:])[d] * 32^-0.5.  dim_head is fixed at 32 like
+ * the reference (DenoisingUNet_arch.py:31-32).  workspace >= uwir_linattn_workspace_bytes(B,n,heads). */
+size_t uwir_linattn_workspace_bytes(int B, int n, int heads);
+int uwir_linear_attention(const void* qkv, int dtype, int ld, int B, int n, int heads, void* out, int out_dtype, int ldo,
+                          void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+
+/* ---- GEGLU gate, U/attention.py:37-44: h [M, 2F] = [value | gate] -> out [M, F] = value * gelu(gate) (exact GELU);
+ * h and out share dtype. */
+int uwir_geglu(const void* h, int dtype, size_t ldh, int M, int F, void* out, size_t ldo, uwir_stream_t stream);
+
+/* ---- prompt weighting softmax(text_mlp(ctx), dim=1) * prompt, U/DenoisingUNet_arch.py:135 -------------------------
+ * y[b,:] = softmax(x[b,:]) * mul (mul [C] or NULL). */
+int uwir_softmax_rows(const float* x, int ldx, int B, int C, const float* mul, float* y, int ldy, uwir_stream_t stream);
+
+/* ---- final_conv Conv2d(nf, out_nc, 3, 1, 1) + crop x[..., :H, :W], U/DenoisingUNet_arch.py:170-172 ----------------
+ * x NHWC fp32 [B,H,W,Cin] (padded size) -> out NCHW fp32 [B,Cout,Ho,Wo] (top-left crop), w repacked [Cout,3,3,Cin],
+ * Cout <= 4. */
+int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                      float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
 
 #ifdef __cplusplus
 }

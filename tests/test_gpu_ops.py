@@ -413,3 +413,89 @@ def test_patchify_and_add_rows(ops):
     exp = a[:, :20] + b[:, 4:]
     ops.add_rows(a[:, :20], b[:, 4:], a[:, :20])
     assert torch.equal(a[:, :20], exp)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_gemm_resblock_epilogue_and_upsample(ops, prec):
+    """IR-SDE UNet pieces: (acc*batch_scale + batch_bias) -> SiLU with strided per-sample vectors; nearest-2x + conv3x3."""
+    g = torch.Generator().manual_seed(15)
+    tol = 2e-5 if prec == "fp32" else 3e-2
+    b, c, h, w, n = 2, 32, 6, 10, 64
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(n, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    ss = torch.randn(b, 4 * n, generator=g)                     # [.. | scale+1 | shift | ..] inside one wide matrix
+    wd = wt.permute(0, 2, 3, 1).reshape(n, -1).to(_wdt(prec)).cuda().contiguous()
+    ssd = ss.cuda()
+    out = torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(to_rows(x), wd, out, B=b, H=h, W=w, C_=c, N=n, KH=3, KW=3, pad=1, batch_scale=ssd[:, n:2 * n],
+                  batch_bias=ssd[:, 2 * n:3 * n], act=ops.ACT_SILU)
+    ref = F.silu(F.conv2d(x.double(), wt.double(), padding=1) * ss[:, n:2 * n].double()[:, :, None, None]
+                 + ss[:, 2 * n:3 * n].double()[:, :, None, None])
+    assert rel(from_rows(out, b, h, w), ref) < tol
+    bias = torch.randn(n, generator=g)
+    up = torch.empty(b * 4 * h * w, n, device="cuda")
+    ops.conv_gemm(to_rows(x), wd, up, B=b, H=h, W=w, C_=c, N=n, KH=3, KW=3, pad=1, ups=1, bias=bias.cuda())
+    refu = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), bias.double(), padding=1)
+    assert rel(from_rows(up, b, 2 * h, 2 * w), refu) < tol
+
+
+def test_groupnorm_affine(ops):
+    g = torch.Generator().manual_seed(16)
+    for (b, c, h, w) in ((2, 128, 4, 4), (1, 256, 32, 32), (3, 64, 5, 7)):
+        x = torch.randn(b, c, h, w, generator=g) * 2 + torch.randn(1, c, 1, 1, generator=g) * 3
+        gw, gb = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        ref = F.group_norm(x.double(), 32, gw.double(), gb.double(), 1e-6)
+        xr = to_rows(x)
+        a, s = torch.empty(b, c, device="cuda"), torch.empty(b, c, device="cuda")
+        ws = torch.empty(max(ops.ln2d_workspace_bytes(b, h * w, c) // 8, 1), dtype=torch.float64, device="cuda")
+        ops.groupnorm_affine(xr, b, h * w, c, 32, 1e-6, gw.cuda(), gb.cuda(), a, s, ws)
+        got = xr.reshape(b, h * w, c) * a[:, None, :] + s[:, None, :]
+        assert rel(from_rows(got.reshape(-1, c), b, h, w), ref) < 2e-5
+
+
+@pytest.mark.parametrize("io", [("fp32", "fp32"), ("bf16", "bf16")])
+def test_linear_attention(ops, io):
+    g = torch.Generator().manual_seed(17)
+    idt, odt = (_wdt(t) for t in io)
+    for (b, n, heads) in ((2, 100, 4), (1, 1500, 4), (2, 7, 2)):
+        hd = heads * 32
+        qkv = (torch.randn(b * n, 3 * hd + 8, generator=g) * 2).to(idt)
+        q, k, v = (qkv[:, i * hd:(i + 1) * hd].double().reshape(b, n, heads, 32).permute(0, 2, 3, 1) for i in range(3))
+        qs = q.softmax(dim=-2) * 32 ** -0.5
+        ks = k.softmax(dim=-1)
+        ctx = torch.einsum("bhdn,bhen->bhde", ks, v / n)
+        ref = torch.einsum("bhde,bhdn->bhen", ctx, qs).permute(0, 3, 1, 2).reshape(b * n, hd)
+        out = torch.full((b * n, hd + 4), 2.0, device="cuda", dtype=odt)
+        ws = torch.empty(ops.linattn_workspace_bytes(b, n, heads) // 4, device="cuda")
+        ops.linear_attention(qkv.cuda(), b, n, heads, out[:, :hd], ws)
+        scale = float(ref.abs().max())
+        assert err(out[:, :hd], ref) < (2e-6 if io[0] == "fp32" else 1e-2) * max(scale, 1e-3) * 10
+        assert float(out[:, hd:].float().min()) == 2.0
+
+
+def test_geglu_softmax_input_tail(ops):
+    g = torch.Generator().manual_seed(18)
+    h = torch.randn(37, 2 * 64, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        o = torch.empty(37, 64, device="cuda", dtype=dt)
+        ops.geglu(h.to(dt).cuda(), o)
+        hh = h.to(dt).double()
+        assert err(o, hh[:, :64] * F.gelu(hh[:, 64:])) < (1e-5 if dt == torch.float32 else 3e-2)
+    x, mul = torch.randn(5, 256, generator=g) * 3, torch.rand(256, generator=g)
+    y = torch.zeros(5, 300, device="cuda")
+    ops.softmax_rows(x.cuda(), mul.cuda(), y[:, 20:276])
+    assert err(y[:, 20:276], torch.softmax(x.double(), dim=1) * mul.double()) < 1e-6
+    # input assembly: cat([xt - cond, cond]) + reflect pad, NHWC with zero-filled channels
+    xt, cond = torch.randn(2, 3, 13, 18, generator=g), torch.randn(2, 3, 13, 18, generator=g)
+    Hp, Wp = 16, 32
+    ref = F.pad(torch.cat([xt - cond, cond], dim=1), (0, Wp - 18, 0, Hp - 13), "reflect")
+    out = torch.empty(2 * Hp * Wp, 8, device="cuda")
+    ops.unet_input(xt.cuda(), cond.cuda(), Hp, Wp, out)
+    got = out.reshape(2, Hp, Wp, 8).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got[:, :6], ref) and float(got[:, 6:].abs().max()) == 0.0
+    # tail conv3x3 + crop, NCHW output
+    feat = torch.randn(2, 32, Hp, Wp, generator=g)
+    wt, bt = torch.randn(3, 32, 3, 3, generator=g) * 0.1, torch.randn(3, generator=g)
+    o = torch.empty(2, 3, 13, 18, device="cuda")
+    ops.tail_conv3x3(to_rows(feat), 2, Hp, Wp, 32, wt.permute(0, 2, 3, 1).contiguous().cuda(), bt.cuda(), 3, o)
+    assert err(o, F.conv2d(feat.double(), wt.double(), bt.double(), padding=1)[..., :13, :18]) < 2e-5

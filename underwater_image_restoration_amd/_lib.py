@@ -35,6 +35,9 @@ class GemmArgs(C.Structure):
         ("blend_out", vp), ("ld_blend_out", ci),
         ("compute", ci),
         ("col_scale", vp),
+        ("batch_scale", vp),
+        ("ups", ci),
+        ("batch_ld", ci),
     ]
 
 
@@ -58,7 +61,14 @@ _SIGS = {
     "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
-    "uwir_ln_rows": (ci, [vp, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, ci, sz, vp]),
+    "uwir_ln_rows": (ci, [vp, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, sz, vp, ci, sz, vp]),
+    "uwir_unet_input": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "uwir_groupnorm_affine": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, sz, vp]),
+    "uwir_linattn_workspace_bytes": (sz, [ci, ci, ci]),
+    "uwir_linear_attention": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp, sz, vp]),
+    "uwir_geglu": (ci, [vp, ci, sz, ci, ci, vp, sz, vp]),
+    "uwir_softmax_rows": (ci, [vp, ci, ci, ci, vp, vp, ci, vp]),
+    "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_add_rows": (ci, [vp, sz, vp, sz, vp, sz, ci, ci, vp]),
     "uwir_patchify": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, sz, vp]),
 }

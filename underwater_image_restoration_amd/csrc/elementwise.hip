@@ -243,6 +243,66 @@ extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, fl
 }
 
 // ------------------------------------------------------------------------------------------
+// GroupNorm (U/models/modules/attention.py:76-77,236,254: 32 groups, eps 1e-6, affine) as a folded
+// per-(b,c) affine a*x + s for the consumer GEMM's normalise-on-load.  Statistics: the per-channel
+// shifted partial sums of ln_partial_kernel, merged per group in fp64 (parallel-variance formula).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ x, int ldx, int n, int C, int groups,
+                                                          const double* __restrict__ part, int nchunks, float eps,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ a_out,
+                                                          float* __restrict__ s_out, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * groups) return;
+    const int b = i / groups, g = i % groups, cg = C / groups;
+    double sum_mean = 0, sum_m2 = 0, sum_mean2 = 0;
+    for (int j = 0; j < cg; ++j) {
+        const int c = g * cg + j;
+        double s = 0, ss = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            const double* p = part + (((size_t)b * nchunks + k) * C + c) * 2;
+            s += p[0];
+            ss += p[1];
+        }
+        const double md = s / n;
+        const double mean = (double)x[(size_t)b * n * ldx + c] + md;
+        sum_mean += mean;
+        sum_mean2 += mean * mean;
+        sum_m2 += ss - s * md;
+    }
+    const double gmean = sum_mean / cg;
+    double var = (sum_m2 + (double)n * (sum_mean2 - cg * gmean * gmean)) / ((double)n * cg);
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int j = 0; j < cg; ++j) {
+        const int c = g * cg + j;
+        const double a = rstd * (double)gamma[c];
+        a_out[(size_t)b * C + c] = (float)a;
+        s_out[(size_t)b * C + c] = (float)((double)beta[c] - gmean * a);
+    }
+}
+
+extern "C" int uwir_groupnorm_affine(const float* x, int ldx, int B, int n, int C, int groups, float eps,
+                                     const float* gamma, const float* beta, float* a_out, float* s_out, void* workspace,
+                                     size_t workspace_bytes, uwir_stream_t stream) {
+    UWIR_CHECK(x && gamma && beta && a_out && s_out && workspace, "groupnorm: null pointer");
+    UWIR_CHECK(B > 0 && B <= 65535 && n > 0 && C > 0 && C % 4 == 0 && groups > 0 && C % groups == 0 && ldx >= C &&
+                   ldx % 4 == 0,
+               "groupnorm: bad shape B=%d n=%d C=%d groups=%d", B, n, C, groups);
+    UWIR_CHECK(workspace_bytes >= uwir_ln2d_workspace_bytes(B, n, C), "groupnorm: workspace too small");
+    int nchunks = ceil_div(n, LN_ROWS_PER_BLOCK);
+    int C4 = C / 4;
+    dim3 grid(nchunks, ceil_div(C4, LN_SLAB_Q), B);
+    hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
+                       nchunks);
+    UWIR_LAUNCH_CHECK("gn_partial");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * groups, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
+                       C, groups, (const double*)workspace, nchunks, eps, gamma, beta, a_out, s_out, B);
+    UWIR_LAUNCH_CHECK("gn_finalize");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // ChannelAttention fold (S/wtb.py:24-28,118-119): x + xn*w with xn = a*x + s  ==  x*(1 + a*w) + s*w,
 // i.e. the residual x enters the proj GEMM epilogue through a per-(b,c) affine.
 // ------------------------------------------------------------------------------------------
@@ -296,6 +356,38 @@ extern "C" int uwir_linear(const float* x, int ldx, int B, int I, const float* W
     hipLaunchKernelGGL(linear_kernel, dim3((unsigned)ceil_div_sz(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        B, I, W, bias, O, act, y, ldy);
     UWIR_LAUNCH_CHECK("linear");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// y[b,:] = softmax(x[b,:]) * mul  -- the prompt weighting of the IR-SDE UNet
+// (U/models/modules/DenoisingUNet_arch.py:135).  One wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, int ldx, int B, int C,
+                                                           const float* __restrict__ mul, float* __restrict__ y,
+                                                           int ldy) {
+    int row = (blockIdx.x * blockDim.x + threadIdx.x) / UWIR_WAVE;
+    int lane = threadIdx.x % UWIR_WAVE;
+    if (row >= B) return;
+    const float* xr = x + (size_t)row * ldx;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += UWIR_WAVE) m = fmaxf(m, xr[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float s = 0.f;
+    for (int c = lane; c < C; c += UWIR_WAVE) s += expf(xr[c] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float inv = 1.f / s;
+    for (int c = lane; c < C; c += UWIR_WAVE) y[(size_t)row * ldy + c] = expf(xr[c] - m) * inv * (mul ? mul[c] : 1.f);
+}
+
+extern "C" int uwir_softmax_rows(const float* x, int ldx, int B, int C, const float* mul, float* y, int ldy,
+                                 uwir_stream_t stream) {
+    UWIR_CHECK(x && y && B > 0 && C > 0 && ldx >= C && ldy >= C, "softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, B, C, mul, y,
+                       ldy);
+    UWIR_LAUNCH_CHECK("softmax_rows");
     return UWIR_OK;
 }
 
@@ -399,18 +491,19 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ a_shift, const float* __restrict__ w,
                                                    const float* __restrict__ bias, int Cout,
                                                    const float* __restrict__ res, float* __restrict__ out,
-                                                   float* __restrict__ preclamp) {
+                                                   float* __restrict__ preclamp, int Ho, int Wo, int do_clamp) {
+    // input map H x W (zero padded conv), outputs only the top-left Ho x Wo crop (NCHW [B,Cout,Ho,Wo])
     const int lane = threadIdx.x % UWIR_WAVE;
     const int C4 = Cin / 4;
     const int items = 9 * C4;  // (tap, quad)
-    size_t npix = (size_t)B * H * W;
+    size_t npix = (size_t)B * Ho * Wo;
     size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) / UWIR_WAVE;
     size_t nwaves = ((size_t)gridDim.x * blockDim.x) / UWIR_WAVE;
     for (size_t p = wave0; p < npix; p += nwaves) {
-        int ox = (int)(p % W);
-        size_t q = p / W;
-        int oy = (int)(q % H);
-        int b = (int)(q / H);
+        int ox = (int)(p % Wo);
+        size_t q = p / Wo;
+        int oy = (int)(q % Ho);
+        int b = (int)(q / Ho);
         float acc[HEAD_MAX_COUT] = {0.f, 0.f, 0.f, 0.f};
         for (int it = lane; it < items; it += UWIR_WAVE) {
             int tap = it / C4, c4 = it % C4;
@@ -443,11 +536,11 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
             float v = acc[0];
 #pragma unroll
             for (int co = 1; co < HEAD_MAX_COUT; ++co) v = (lane == co) ? acc[co] : v;
-            size_t o = (((size_t)b * Cout + lane) * H + oy) * W + ox;
+            size_t o = (((size_t)b * Cout + lane) * Ho + oy) * Wo + ox;
             v += (bias ? bias[lane] : 0.f);
             if (res) v += res[o];
             if (preclamp) preclamp[o] = v;
-            out[o] = fminf(fmaxf(v, 0.f), 1.f);
+            out[o] = do_clamp ? fminf(fmaxf(v, 0.f), 1.f) : v;
         }
     }
 }
@@ -465,8 +558,24 @@ extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, i
     size_t blocks = ceil_div_sz(npix, 4);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, B, H, W, Cin,
-                       a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw);
+                       a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw, H, W, 1);
     UWIR_LAUNCH_CHECK("head");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                                 int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
+    UWIR_CHECK(x && w && out_nchw, "tail: null pointer");
+    UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
+                   ldx % 4 == 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W,
+               "tail: bad shape (Cout<=%d, crop within the map)", HEAD_MAX_COUT);
+    size_t npix = (size_t)B * Ho * Wo;
+    size_t blocks = ceil_div_sz(npix, 4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, B, H, W, Cin,
+                       (const float*)nullptr, (const float*)nullptr, w, bias, Cout, (const float*)nullptr, out_nchw,
+                       (float*)nullptr, Ho, Wo, 0);
+    UWIR_LAUNCH_CHECK("tail");
     return UWIR_OK;
 }
 

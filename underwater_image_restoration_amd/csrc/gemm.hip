@@ -39,6 +39,7 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
     const int N = g.N;
     const int OHW = g.OH * g.OW;
     const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
+    const int bld = g.batch_ld ? g.batch_ld : N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int m = m_base + i * 16 + fr;
@@ -52,8 +53,12 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
             if (n >= N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (g.batch_scale) {
+                float4 t = load4(g.batch_scale + (size_t)b * bld + n);
+                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
+            }
             if (g.batch_bias) {
-                float4 t = load4(g.batch_bias + (size_t)b * N + n);
+                float4 t = load4(g.batch_bias + (size_t)b * bld + n);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
             if (g.act != UWIR_ACT_NONE) {
@@ -159,11 +164,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
             if (!is1x1) { tap = k / C; ch = k - tap * C; }
             int ky = tap / g.KW, kx = tap - ky * g.KW;
             int iy = a_y[i] + ky, ix = a_x[i] + kx;
-            ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            // ups = 1: the conv runs on the nearest-neighbour 2x upsampled image (never materialised)
+            ok = ok && iy >= 0 && iy < (g.H << g.ups) && ix >= 0 && ix < (g.W << g.ups);
             ra_in[i] = ok;
             ra_c[i] = ch;
             if (ok) {
-                const TA* src = Aptr + (((size_t)a_b[i] * g.H + iy) * g.W + ix) * g.lda + ch;
+                const TA* src = Aptr + (((size_t)a_b[i] * g.H + (iy >> g.ups)) * g.W + (ix >> g.ups)) * g.lda + ch;
                 if constexpr (sizeof(TA) == 4) {
                     ra[i].lo = *reinterpret_cast<const float4*>(src);
                     if constexpr (EPC == 8) ra[i].hi = *reinterpret_cast<const float4*>(src + 4);
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
 
 static bool glds_eligible(const uwir_gemm_args& g, int K) {
     return g.compute == UWIR_BF16 && g.a_dtype == UWIR_BF16 && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 &&
-           !g.a_scale && K % 64 == 0 && g.N > 64 && g.lda % 8 == 0;
+           !g.a_scale && K % 64 == 0 && g.N > 64 && g.lda % 8 == 0 && !g.ups;
 }
 
 
@@ -418,8 +424,12 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     UWIR_CHECK(g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.N > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0 &&
                    g.pad >= 0 && g.OH > 0 && g.OW > 0,
                "conv_gemm: bad geometry");
-    UWIR_CHECK(g.H + 2 * g.pad >= g.KH && g.W + 2 * g.pad >= g.KW &&
-                   g.OH <= (g.H + 2 * g.pad - g.KH) / g.stride + 1 && g.OW <= (g.W + 2 * g.pad - g.KW) / g.stride + 1,
+    UWIR_CHECK(g.ups == 0 || g.ups == 1, "conv_gemm: ups must be 0 or 1");
+    UWIR_CHECK(g.batch_ld == 0 || (g.batch_ld >= g.N && g.batch_ld % 4 == 0), "conv_gemm: bad batch_ld");
+    UWIR_CHECK((((uintptr_t)g.batch_bias | (uintptr_t)g.batch_scale) & 15) == 0, "conv_gemm: batch_bias/batch_scale must be 16-byte aligned");
+    const int Hv = g.H << g.ups, Wv = g.W << g.ups;
+    UWIR_CHECK(Hv + 2 * g.pad >= g.KH && Wv + 2 * g.pad >= g.KW &&
+                   g.OH <= (Hv + 2 * g.pad - g.KH) / g.stride + 1 && g.OW <= (Wv + 2 * g.pad - g.KW) / g.stride + 1,
                "conv_gemm: output size exceeds the convolution's extent");
     UWIR_CHECK(g.compute == UWIR_F32 || g.compute == UWIR_BF16, "conv_gemm: bad compute dtype");
     UWIR_CHECK(g.w_dtype == g.compute, "conv_gemm: weight dtype must equal compute dtype");

@@ -13,7 +13,7 @@ template <typename TY>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ x, size_t ldx, int M, int C4,
                                                       const float* __restrict__ add, int add_period, int add_ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, TY* __restrict__ y, size_t ldy) {
+                                                      float eps, const float* res, size_t ldr, TY* y, size_t ldy) {
     const int lane = threadIdx.x % UWIR_WAVE;
     const int row = blockIdx.x * (blockDim.x / UWIR_WAVE) + threadIdx.x / UWIR_WAVE;
     if (row >= M) return;  // whole wave
@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = 1.f / sqrtf(q * invC + eps);
     TY* yr = y + (size_t)row * ldy;
+    const float* rr = res ? res + (size_t)row * ldr : nullptr;
     for (int c4 = lane; c4 < C4; c4 += UWIR_WAVE) {
         float4 v = ld(c4), g = load4(gamma + 4 * c4);
         float4 b = beta ? load4(beta + 4 * c4) : make_float4(0, 0, 0, 0);
@@ -54,26 +55,31 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
         o.y = (v.y - mean) * rstd * g.y + b.y;
         o.z = (v.z - mean) * rstd * g.z + b.z;
         o.w = (v.w - mean) * rstd * g.w + b.w;
+        if (rr) {  // Residual(PreNorm(...)) tail: LN(out) + x (U/models/modules/module_util.py:27-33,167,185)
+            float4 r = load4(rr + 4 * c4);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         store4(yr + 4 * c4, o);
     }
 }
 
 extern "C" int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
-                            const float* gamma, const float* beta, float eps, void* y, int y_dtype, size_t ldy,
-                            uwir_stream_t stream) {
+                            const float* gamma, const float* beta, float eps, const float* res, size_t ldr, void* y,
+                            int y_dtype, size_t ldy, uwir_stream_t stream) {
     UWIR_CHECK(x && gamma && y, "ln_rows: null pointer");
     UWIR_CHECK(M > 0 && C > 0 && C % 4 == 0 && ldx >= (size_t)C && ldx % 4 == 0 && ldy >= (size_t)C && ldy % 4 == 0,
                "ln_rows: bad shape M=%d C=%d", M, C);
     UWIR_CHECK(!add || (add_period > 0 && add_ld >= C && add_ld % 4 == 0), "ln_rows: bad add table");
+    UWIR_CHECK(!res || (ldr >= (size_t)C && ldr % 4 == 0), "ln_rows: bad residual stride");
     UWIR_CHECK(y_dtype == UWIR_F32 || y_dtype == UWIR_BF16, "ln_rows: bad output dtype");
     UWIR_CHECK((const void*)x != (const void*)y || y_dtype == UWIR_F32, "ln_rows: in-place needs an fp32 output");
     dim3 grid(ceil_div(M, 4));
     if (y_dtype == UWIR_F32)
         hipLaunchKernelGGL(ln_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, C / 4, add,
-                           add_period, add_ld, gamma, beta, eps, (float*)y, ldy);
+                           add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy);
     else
         hipLaunchKernelGGL(ln_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, C / 4, add,
-                           add_period, add_ld, gamma, beta, eps, (bf16_t*)y, ldy);
+                           add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy);
     UWIR_LAUNCH_CHECK("ln_rows");
     return UWIR_OK;
 }

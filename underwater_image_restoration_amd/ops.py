@@ -106,21 +106,27 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
               N: int, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, OH: Optional[int] = None,
               OW: Optional[int] = None, a_scale=None, a_shift=None, bias=None, batch_bias=None, act: int = ACT_NONE,
               res=None, res_scale=None, res_shift=None, store_mode: int = 0, blend_t=None, blend_f=None,
-              blend_out=None, col_scale=None) -> None:
+              blend_out=None, col_scale=None, batch_scale=None, ups: int = 0) -> None:
     """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h."""
     lib = _lib.load()
-    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale)
+    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale, batch_scale)
     g = GemmArgs()
     g.A, g.a_dtype, g.lda = _p(A), _dt(A), _ld(A)
     g.B, g.H, g.W, g.C = B, H, W, C_
     g.KH, g.KW, g.stride, g.pad = KH, KW, stride, pad
-    g.OH = OH if OH is not None else (H + 2 * pad - KH) // stride + 1
-    g.OW = OW if OW is not None else (W + 2 * pad - KW) // stride + 1
+    g.OH = OH if OH is not None else ((H << ups) + 2 * pad - KH) // stride + 1
+    g.OW = OW if OW is not None else ((W << ups) + 2 * pad - KW) // stride + 1
     g.a_scale, g.a_shift = _p(a_scale), _p(a_shift)
     if Wt.dim() != 2 or not Wt.is_contiguous() or Wt.shape[0] != N or Wt.shape[1] != KH * KW * C_:
         raise ValueError(f"conv_gemm: weight must be contiguous [N, KH*KW*C], got {tuple(Wt.shape)}")
     g.Wt, g.w_dtype, g.N = _p(Wt), _dt(Wt), N
     g.bias, g.batch_bias, g.act = _p(bias), _p(batch_bias), act
+    g.batch_ld = 0
+    for t in (batch_bias, batch_scale):  # [B, N] views; may be column slices of one wide matrix
+        if t is not None:
+            if t.shape[0] != B or t.shape[1] != N or (g.batch_ld not in (0, _ld(t))):
+                raise ValueError("conv_gemm: batch_bias / batch_scale must be [B, N] views sharing a row stride")
+            g.batch_ld = _ld(t)
     g.res, g.ldr = _p(res), (0 if res is None else _ld(res))
     g.res_scale, g.res_shift = _p(res_scale), _p(res_shift)
     g.out = _p(out)
@@ -133,6 +139,7 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
     g.blend_out, g.ld_blend_out = _p(blend_out), (0 if blend_out is None else _ld(blend_out))
     g.compute = _dt(Wt)
     g.col_scale = _p(col_scale)
+    g.batch_scale, g.ups = _p(batch_scale), ups
     _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
 
 
@@ -235,9 +242,10 @@ def gemm(A: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor, **kw) -> None:
     conv_gemm(A, Wt, out, B=1, H=1, W=A.shape[0], C_=Wt.shape[1], N=Wt.shape[0], **kw)
 
 
-def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, add=None, add_period: int = 0) -> None:
-    """y[m] = LayerNorm_C(x[m] + add[m % add_period]) * gamma + beta; x fp32 [M, C] view, y fp32/bf16."""
-    _f32(x, gamma, beta, add)
+def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, add=None, add_period: int = 0,
+            res=None) -> None:
+    """y[m] = LayerNorm_C(x[m] + add[m % add_period]) * gamma + beta (+ res[m]); x fp32 [M, C] view, y fp32/bf16."""
+    _f32(x, gamma, beta, add, res)
     lib = _lib.load()
     M, C_ = x.shape
     if y.shape[0] != M or y.shape[1] != C_ or gamma.numel() != C_:
@@ -245,7 +253,8 @@ def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, ad
     if add is not None and (add.shape[0] != add_period or add.shape[1] != C_):
         raise ValueError("ln_rows: add table must be [add_period, C]")
     _lib.check(lib.uwir_ln_rows(_p(x), _ld(x), M, C_, _p(add), add_period, 0 if add is None else _ld(add), _p(gamma),
-                                _p(beta), eps, _p(y), _dt(y), _ld(y), _stream()), "ln_rows")
+                                _p(beta), eps, _p(res), 0 if res is None else _ld(res), _p(y), _dt(y), _ld(y),
+                                _stream()), "ln_rows")
 
 
 def patchify(img: torch.Tensor, P: int, out: torch.Tensor) -> None:
@@ -264,3 +273,58 @@ def add_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
     if b.shape != a.shape or out.shape != a.shape:
         raise ValueError("add_rows: shape mismatch")
     _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C_, _stream()), "add_rows")
+
+
+def unet_input(xt: torch.Tensor, cond: torch.Tensor, Hp: int, Wp: int, out: torch.Tensor) -> None:
+    """out [B*Hp*Wp, Cp] = NHWC cat([xt - cond, cond]) with reflect padding to (Hp, Wp), channels zero-filled to Cp."""
+    _f32(xt, cond, out)
+    lib = _lib.load()
+    if xt.shape != cond.shape or xt.dim() != 4 or not xt.is_contiguous() or not cond.is_contiguous():
+        raise ValueError("unet_input: xt / cond must be contiguous NCHW tensors of one shape")
+    B, Cin, H, W = xt.shape
+    if not out.is_contiguous() or out.shape[0] != B * Hp * Wp:
+        raise ValueError("unet_input: bad output buffer")
+    _lib.check(lib.uwir_unet_input(_p(xt), _p(cond), B, Cin, H, W, Hp, Wp, out.shape[1], _p(out), _stream()), "unet_input")
+
+
+def groupnorm_affine(x: torch.Tensor, B: int, n: int, C_: int, groups: int, eps: float, gamma, beta, a_out, s_out,
+                     workspace: torch.Tensor) -> None:
+    _f32(x, gamma, beta, a_out, s_out)
+    lib = _lib.load()
+    _lib.check(lib.uwir_groupnorm_affine(_p(x), _ld(x), B, n, C_, groups, eps, _p(gamma), _p(beta), _p(a_out), _p(s_out),
+                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream()),
+               "groupnorm_affine")
+
+
+def linattn_workspace_bytes(B: int, n: int, heads: int) -> int:
+    return int(_lib.load().uwir_linattn_workspace_bytes(B, n, heads))
+
+
+def linear_attention(qkv: torch.Tensor, B: int, n: int, heads: int, out: torch.Tensor, workspace: torch.Tensor) -> None:
+    lib = _lib.load()
+    _lib.check(lib.uwir_linear_attention(_p(qkv), _dt(qkv), _ld(qkv), B, n, heads, _p(out), _dt(out), _ld(out),
+                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream()),
+               "linear_attention")
+
+
+def geglu(h: torch.Tensor, out: torch.Tensor) -> None:
+    lib = _lib.load()
+    M, F2 = h.shape
+    if _dt(h) != _dt(out) or out.shape[0] != M or out.shape[1] * 2 != F2:
+        raise ValueError("geglu: h must be [M, 2F] and out [M, F] of one dtype")
+    _lib.check(lib.uwir_geglu(_p(h), _dt(h), _ld(h), M, F2 // 2, _p(out), _ld(out), _stream()), "geglu")
+
+
+def softmax_rows(x: torch.Tensor, mul, y: torch.Tensor) -> None:
+    _f32(x, mul, y)
+    lib = _lib.load()
+    B, C_ = x.shape
+    _lib.check(lib.uwir_softmax_rows(_p(x), _ld(x), B, C_, _p(mul), _p(y), _ld(y), _stream()), "softmax_rows")
+
+
+def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cout: int, out_nchw: torch.Tensor) -> None:
+    _f32(x, w, bias, out_nchw)
+    lib = _lib.load()
+    Ho, Wo = out_nchw.shape[2], out_nchw.shape[3]
+    _lib.check(lib.uwir_tail_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream()),
+               "tail_conv3x3")
