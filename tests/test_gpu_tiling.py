@@ -1,0 +1,41 @@
+"""GPU parity of halo-tiled restoration: HIP student on batched windows + stitch (product) vs the tiling oracle
+(reference-equivalent forward on each window, stitched by ownership)."""
+import pytest
+import torch
+
+from oracle import student_ref as R
+from oracle import tiling_ref as TR
+from tests.helpers import max_abs
+from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("with_masks", [True, False])
+def test_tiled_student_matches_tiling_oracle(with_masks):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.tiling import TiledRestorer
+    M = 10 if with_masks else 0
+    mk = dict(base_channels=16, num_levels=3, blocks_per_level=1, cond_dim=20, num_masks=M, num_degradation_types=None)
+    sd = synth_state_dict(student_param_shapes(**mk), seed=11)
+    model = NAFNetWFIGate(**mk, precision="fp32")
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    x, z, m = synth_student_inputs(2, 48, 80, 20, M, mask_hw=(7, 7), seed=77)   # 2 frames, 2 x 4 cells of 16 px + halo 8
+    sd64 = {k: v.double() for k, v in sd.items()}
+
+    def ref_fn(xw, c, mw):
+        with torch.no_grad():
+            return R.student_forward(sd64, xw, c, mw, blocks_per_level=1)[0]
+
+    ref = TR.tiled_forward(ref_fn, x.double(), z.double(), None if m is None else m.double(), 32, 8)
+    restorer = TiledRestorer(model, tile=32, halo=8, max_batch=5)
+    out = restorer(x.cuda(), z.cuda(), None if m is None else m.cuda())
+    e = max_abs(out.cpu().numpy(), ref.numpy())
+    print(f"\n[tiled student masks={with_masks}] 48x80 frame, 32-px windows, halo 8: max abs err {e:.3e}")
+    assert out.shape == x.shape and e < 1e-4
+    # tiling really changes the function (global norms / attention see one window): whole-frame result differs
+    whole = model(x.cuda(), z.cuda(), None if m is None else m.cuda())[0]
+    assert float((whole - out).abs().max()) > 1e-3

@@ -113,3 +113,23 @@ def test_unet_api_errors():
         m(x.cpu(), x.cpu(), 5)
     with pytest.raises(ValueError):
         ConditionalUNet(3, 3, 16)
+
+
+def test_denoising_model_wrapper():
+    """feed_data / test / get_current_visuals as U/test.py:119-127 drives them."""
+    cfg, sd, model, (xt, mu, text, image), g = _setup("lin", "fp32")
+    from underwater_image_restoration_amd.denoising import DenoisingModel
+    from underwater_image_restoration_amd.sde import IRSDE
+    sde = IRSDE(max_sigma=50, T=100, sample_T=4, schedule="cosine", eps=0.005, device="cuda")  # 4 sampling steps
+    sde.set_model(model)
+    dm = DenoisingModel(model)
+    tape = torch.randn(4, *xt.shape, generator=torch.Generator().manual_seed(2)).cuda()
+    dm.feed_data(xt, mu, GT=mu, text_context=text.cuda(), image_context=None)
+    dm.test(sde, mode="posterior", noise_tape=tape)
+    vis = dm.get_current_visuals()
+    assert set(vis) == {"Input", "Output", "GT"} and vis["Output"].shape == xt.shape[1:] and not vis["Output"].is_cuda
+    a = dm.output.clone()
+    dm.test(sde, mode="anything-else-is-posterior", noise_tape=tape)
+    assert torch.equal(a, dm.output)
+    dm.test(sde, mode="sde", noise_tape=tape)
+    assert not torch.equal(a, dm.output) and torch.isfinite(dm.output).all()

@@ -1,0 +1,104 @@
+"""One-process-per-GPU sharding of the restoration path over RCCL/xGMI (``torch.distributed``; backend "nccl" on the
+GPU box IS RCCL, "gloo" in the CPU tests).
+
+The path shards by independent units -- images of a dataset (BASELINE config 5) or halo windows of one large frame
+(config 3) -- so there is NO data-path collective: weights are replicated, every rank restores its contiguous
+block of units, and RCCL is only used afterwards to (optionally) gather outputs to rank 0 and to all-reduce a small
+fp64 metrics vector (the counterpart of the reference's only inference-side collectives,
+underwater_ir/student/train_student.py:646 all_reduce and :715 barrier).  xGMI is point-to-point: the 7-to-1
+gather uses each sender's own direct link to the root.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_items: int, rank: Optional[int] = None, world_size: Optional[int] = None) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of ``ceil(n/world)`` items for ``rank`` (trailing ranks may get fewer / none)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    per = math.ceil(n_items / world_size) if n_items > 0 else 0
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)
+
+
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Gather per-rank blocks (split along dim 0 by ``shard_range``) onto ``dst``; other ranks get None.
+    Blocks are padded to the common block size so a plain gather works for ragged tails."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    per = math.ceil(n_total / ws)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(ws):
+        lo, hi = shard_range(n_total, r, ws)
+        parts.append(bufs[r][:hi - lo])
+    return torch.cat(parts, dim=0)
+
+
+def allreduce_metrics(values: Sequence[float], device) -> List[float]:
+    """SUM all-reduce of a small fp64 vector, e.g. [psnr_sum, ssim_sum, count] (train_student.py:646 uses AVG of one
+    scalar; sums + count give exact dataset means for ragged shards)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if world()[1] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def psnr_sum(restored: torch.Tensor, target: torch.Tensor) -> Tuple[float, int]:
+    """Per-image PSNR 10*log10(1/mse) capped at 100 dB (train_student.py:91-95), summed over the local batch."""
+    mse = ((restored.double() - target.double()) ** 2).flatten(1).mean(dim=1)
+    p = torch.where(mse < 1e-10, torch.full_like(mse, 100.0), 10.0 * torch.log10(1.0 / mse.clamp_min(1e-300)))
+    return float(p.sum()), int(p.numel())
+
+
+@torch.no_grad()
+def restore_dataset_sharded(restore_fn: Callable[[int, int], torch.Tensor], n_images: int, gather: bool = False,
+                            dst: int = 0):
+    """``restore_fn(lo, hi)`` restores images [lo, hi) (any batching inside) and returns them stacked on dim 0.
+    Every rank handles ``shard_range(n_images)``; outputs stay sharded unless ``gather``.  -> (local, gathered)."""
+    lo, hi = shard_range(n_images)
+    local = restore_fn(lo, hi)
+    if local.shape[0] != hi - lo:
+        raise ValueError("restore_fn returned a wrong number of images")
+    return local, (gather_rows(local, n_images, dst) if gather else None)
+
+
+@torch.no_grad()
+def restore_frame_sharded(restorer, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None,
+                          dst: int = 0) -> Optional[torch.Tensor]:
+    """One large frame, windows sharded over the ranks (``restorer`` is a tiling.TiledRestorer; every rank holds the
+    full input frame, 24.9 MB at 1080p).  The restored windows are gathered to ``dst`` and stitched there."""
+    rank, ws = world()
+    H, W = x.shape[-2:]
+    tiles = restorer.windows(x)
+    if tiles is None or ws == 1:
+        return restorer(x, cond, masks)
+    lo, hi = shard_range(len(tiles))
+    fm = restorer.frame_masks(masks, H, W)
+    T = restorer.tile
+    if hi > lo:
+        win = restorer.run_windows(x, cond, fm, tiles[lo:hi])            # (B, n_local, C, T, T)
+    else:
+        win = torch.empty(x.shape[0], 0, x.shape[1], T, T, dtype=torch.float32, device=x.device)
+    allw = gather_rows(win.transpose(0, 1).contiguous(), len(tiles), dst)  # windows on dim 0
+    if rank != dst:
+        return None
+    return restorer.stitch(allw.transpose(0, 1), tiles, H, W)

@@ -1,0 +1,114 @@
+"""Halo-overlapped tiling of large frames (BASELINE config 3: 1920x1080 on one GPU; tiles also shard across GPUs).
+
+The reference has NO tiling: it resizes to ``img_size`` or feeds whole frames, which is
+infeasible at 1080p (the CFC attention matrix alone would be ~4.3 TB).  Every global op of the student
+(LayerNorm2d statistics, FFT, both attentions, channel attention) sees only its window, so tiling CHANGES the
+function.  The semantics are therefore defined here, and the parity oracle (oracle/tiling_ref.py) is "the reference
+forward applied to each identical window, stitched by the same rule":
+
+  * the frame is cut into core cells of ``core = tile - 2*halo`` pixels; cell (i, j) owns the output pixels
+    ``[i*core, (i+1)*core) x [j*core, (j+1)*core)`` (clipped to the frame);
+  * its window is the ``tile x tile`` region around the cell (``halo`` pixels on every side), shifted so that it
+    lies inside the frame; all windows have the same size, so they batch;
+  * ``cond`` (z_d) is shared by all windows of a frame; masks are bilinearly resized (align_corners=False) to the
+    frame once and cropped per window;
+  * every output pixel is taken from the window of the cell that owns it (no blending).
+A frame that is smaller than ``tile`` in either dimension is processed whole.
+"""
+from __future__ import annotations
+
+from typing import List, NamedTuple, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+class Tile(NamedTuple):
+    wy: int   # window origin (inside the frame)
+    wx: int
+    cy0: int  # owned output region [cy0, cy1) x [cx0, cx1)
+    cy1: int
+    cx0: int
+    cx1: int
+
+
+def plan_tiles(H: int, W: int, tile: int = 256, halo: int = 32) -> List[Tile]:
+    if tile % 8 or halo < 0 or tile - 2 * halo <= 0:
+        raise ValueError("tile must be a multiple of 8 and larger than 2*halo")
+    if H < tile or W < tile:
+        raise ValueError("frame smaller than one tile: process it whole")
+    core = tile - 2 * halo
+    tiles = []
+    for cy0 in range(0, H, core):
+        cy1 = min(cy0 + core, H)
+        wy = min(max(cy0 - halo, 0), H - tile)
+        for cx0 in range(0, W, core):
+            cx1 = min(cx0 + core, W)
+            wx = min(max(cx0 - halo, 0), W - tile)
+            tiles.append(Tile(wy, wx, cy0, cy1, cx0, cx1))
+    return tiles
+
+
+class TiledRestorer:
+    """``restorer(x, cond, masks=None) -> restored`` for frames of any size (H, W multiples of 8) by running
+    ``model`` (a NAFNetWFIGate) on batches of halo-overlapped windows.  ``tile_slice`` = (rank, world) restricts
+    the call to this rank's share of the windows (multi-GPU: see shard.restore_frame_sharded)."""
+
+    def __init__(self, model, tile: int = 256, halo: int = 32, max_batch: int = 32) -> None:
+        self.model, self.tile, self.halo, self.max_batch = model, tile, halo, max_batch
+
+    def windows(self, x: torch.Tensor) -> Optional[List[Tile]]:
+        H, W = x.shape[-2:]
+        if H < self.tile or W < self.tile:
+            return None
+        return plan_tiles(H, W, self.tile, self.halo)
+
+    @torch.no_grad()
+    def frame_masks(self, masks: Optional[torch.Tensor], H: int, W: int) -> Optional[torch.Tensor]:
+        """(B,M,hm,wm) -> (B,M,H,W): F.interpolate(bilinear, align_corners=False) on the device kernel."""
+        if masks is None:
+            return None
+        B, M = masks.shape[:2]
+        rows = torch.empty(B * H * W, M, dtype=torch.float32, device=masks.device)
+        ops.bilinear_nchw_to_nhwc(masks.contiguous().float(), rows, H, W)
+        return rows.view(B, H, W, M).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def run_windows(self, x, cond, fmasks, tiles: List[Tile]) -> torch.Tensor:
+        """-> (B, len(tiles), C, tile, tile) restored windows."""
+        B, T = x.shape[0], self.tile
+        outs = []
+        for b in range(B):
+            frame_out = []
+            for s in range(0, len(tiles), self.max_batch):
+                chunk = tiles[s:s + self.max_batch]
+                xb = torch.stack([x[b, :, t.wy:t.wy + T, t.wx:t.wx + T] for t in chunk]).contiguous()
+                cb = cond[b:b + 1].expand(len(chunk), -1).contiguous()
+                mb = None if fmasks is None else torch.stack(
+                    [fmasks[b, :, t.wy:t.wy + T, t.wx:t.wx + T] for t in chunk]).contiguous()
+                o, _, _ = self.model(xb, cb, mb)
+                frame_out.append(o)  # `restored` is freshly allocated by every forward
+            outs.append(torch.cat(frame_out, dim=0))
+        return torch.stack(outs)
+
+    @staticmethod
+    def stitch(win: torch.Tensor, tiles: List[Tile], H: int, W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, _, C = win.shape[:3]
+        out = torch.empty(B, C, H, W, dtype=win.dtype, device=win.device) if out is None else out
+        for i, t in enumerate(tiles):
+            out[:, :, t.cy0:t.cy1, t.cx0:t.cx1] = win[:, i, :, t.cy0 - t.wy:t.cy1 - t.wy, t.cx0 - t.wx:t.cx1 - t.wx]
+        return out
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x.dim() != 4:
+            raise ValueError("Input must be (B, C, H, W).")
+        H, W = x.shape[-2:]
+        if H % 8 or W % 8:
+            raise ValueError("H and W must be multiples of 8")
+        tiles = self.windows(x)
+        if tiles is None:
+            return self.model(x, cond, masks)[0]
+        fm = self.frame_masks(masks, H, W)
+        return self.stitch(self.run_windows(x, cond, fm, tiles), tiles, H, W)
