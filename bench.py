@@ -63,6 +63,9 @@ def main() -> None:
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", default="student", choices=["student", "tiled1080", "sde", "dataset512"],
+                    help="student = BASELINE configs[1] (the headline line); the others are configs[2], [3], [4]")
+    ap.add_argument("--sde-steps", type=int, default=100)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=256)
     args = ap.parse_args()
@@ -99,6 +102,52 @@ def main() -> None:
         _, z_d = clip.encode_image(clip_in, control=True)   # U/test.py:114-117: degra_features condition the net
         return model(x, z_d, m)
 
+    mp_per_step = args.batch * args.size * args.size / 1e6
+    wl_name = None
+    if args.workload == "tiled1080":     # configs[2]: one 1920x1080 frame through 256-px windows with a 32-px halo
+        from underwater_image_restoration_amd.tiling import TiledRestorer
+        frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(3 + rank)).cuda()
+        restorer = TiledRestorer(model, tile=256, halo=32, max_batch=30)
+        m1, c1 = m[:1].contiguous(), clip_in[:1].contiguous()
+
+        def step():  # noqa: F811
+            _, z_d = clip.encode_image(c1, control=True)
+            return restorer(frame, z_d, m1)
+        mp_per_step = 1080 * 1920 / 1e6
+        wl_name = (f"BASELINE configs[2]: 1920x1080 frame, 60 halo windows of 256 px (32-px halo), DA-CLIP z_d, "
+                   f"{args.precision}")
+    elif args.workload == "sde":        # configs[3]: IR-SDE reverse sampling, B=8 at 256x256, T steps
+        from underwater_image_restoration_amd.sde import IRSDE
+        from underwater_image_restoration_amd.synth import unet_param_shapes
+        from underwater_image_restoration_amd.unet import ConditionalUNet
+        unet = ConditionalUNet(3, 3, 64, [1, 2, 4, 8], 512, True, True, precision=args.precision)
+        unet.load_state_dict(synth_state_dict(unet_param_shapes(), seed=2))
+        unet = unet.cuda().eval()
+        sde = IRSDE(max_sigma=50, T=100, sample_T=args.sde_steps, schedule="cosine", eps=0.005, device="cuda")
+        sde.set_model(unet)
+        Bs = 8
+        mu = x[:Bs].contiguous()
+        sde.set_mu(mu)
+        cin = clip_in[:Bs].contiguous()
+
+        def step():  # noqa: F811
+            img_f, deg_f = clip.encode_image(cin, control=True)
+            xt = sde.noise_state(mu)
+            return sde.reverse_posterior(xt, text_context=deg_f, image_context=img_f)
+        mp_per_step = Bs * args.size * args.size / 1e6
+        wl_name = (f"BASELINE configs[3]: IR-SDE reverse_posterior, {args.sde_steps} ConditionalUNet steps, batch {Bs} at "
+                   f"{args.size}x{args.size}, DA-CLIP contexts, {args.precision}")
+    elif args.workload == "dataset512":  # configs[4]: 512x512 images, sharded over the ranks (weak scaling per step)
+        Bd = 4
+        xd, _, md = synth_student_inputs(Bd, 512, 512, 512, 10, mask_hw=(7, 7), seed=99 + rank)
+        xd, md, cd = xd.cuda(), md.cuda(), clip_in[:Bd].contiguous()
+
+        def step():  # noqa: F811
+            _, z_d = clip.encode_image(cd, control=True)
+            return model(xd, z_d, md)
+        mp_per_step = Bd * 512 * 512 / 1e6
+        wl_name = f"BASELINE configs[4]: 512x512 images, {Bd}/GPU per step, DA-CLIP z_d, {args.precision}"
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -122,7 +171,7 @@ def main() -> None:
         elapsed = float(t.item())
 
     if rank == 0:
-        mp = world * args.batch * args.size * args.size / 1e6 * args.steps
+        mp = world * mp_per_step * args.steps
         # dominant kernel: level-0 WTB flash attention (12 heads x hd 16, n = (S/2)^2): most FLOPs of the path
         n0 = (args.size // 2) ** 2
         dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
@@ -136,7 +185,7 @@ def main() -> None:
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}
         cpu = None
-        if args.cpu_baseline != "skip" and world == 1:
+        if args.cpu_baseline != "skip" and world == 1 and args.workload == "student":
             threads = min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(mk, sd, clip_sd, args.cpu_size, threads)
         line = {
@@ -152,6 +201,9 @@ def main() -> None:
                        "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if wl_name is not None:
+            line["config"] = {"workload": wl_name, "sharding": f"independent units x{world}"}
+            line["roofline"] = None  # the roofline leg is defined for the headline workload only
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
