@@ -499,3 +499,29 @@ def test_geglu_softmax_input_tail(ops):
     o = torch.empty(2, 3, 13, 18, device="cuda")
     ops.tail_conv3x3(to_rows(feat), 2, Hp, Wp, 32, wt.permute(0, 2, 3, 1).contiguous().cuda(), bt.cuda(), 3, o)
     assert err(o, F.conv2d(feat.double(), wt.double(), bt.double(), padding=1)[..., :13, :18]) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 200, 3, 16, 1), (1, 333, 4, 16, 2), (1, 130, 2, 32, 1), (1, 97, 2, 64, 2), (1, 4096, 2, 16, 1)])
+def test_flash_attn_bf16_fast_path_and_fallback(ops, cfg):
+    """bf16 fast path (a-priori bound |q| max|k| as the softmax shift) vs the online-max loop, and the automatic
+    fallback when the bound is too large for a fixed shift (scores of several hundred log2 units)."""
+    b, n, heads, hd, nv = cfg
+    g = torch.Generator().manual_seed(19)
+    wdt = heads * hd
+    for amp, expect_fast in ((1.0, True), (12.0, False)):
+        q, k = (torch.randn(b * n, wdt, generator=g) * amp).bfloat16(), (torch.randn(b * n, wdt, generator=g) * amp).bfloat16()
+        vs = [torch.randn(b * n, wdt, generator=g).bfloat16() for _ in range(nv)]
+        refs = _attn_ref(q.double().reshape(b, n, wdt), k.double().reshape(b, n, wdt), [t.double().reshape(b, n, wdt) for t in vs],
+                         heads, hd)
+        outs = {}
+        for fast in (True, False):
+            o = [torch.empty(b * n, wdt, device="cuda") for _ in range(nv)]
+            ops.flash_attn(q.cuda(), k.cuda(), vs[0].cuda(), vs[1].cuda() if nv == 2 else None, b, n, heads, hd,
+                           1.0 / math.sqrt(hd), o[0], o[1] if nv == 2 else None, fast=fast)
+            outs[fast] = o
+            if expect_fast:  # (at amp 12 the softmax is near one-hot and bf16 score rounding alone moves O(1) mass)
+                for got, ref in zip(o, refs):
+                    assert err(got.reshape(b, n, wdt), ref) < 3e-2, (amp, fast)
+        if not expect_fast:  # bound > 60 everywhere: the fast call must have taken the very same online-max code
+            for a_, b_ in zip(outs[True], outs[False]):
+                assert torch.equal(a_, b_)

@@ -19,6 +19,7 @@ struct AttnP {
     int ldq, ldk, ldv[2], ldo[2];
     int n, heads, hd, out_dtype;
     float c;  // scale * log2(e); 1 when q is pre-scaled
+    const float* kmax2;  // optional [B*heads]: max over keys of |k|^2 (bf16 fast path: a-priori score bound)
 };
 
 #define AT_KT 64
@@ -143,6 +144,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     for (int g = 0; g < DG; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[g][r] = 0.f;
+    f32x16 Lacc;  // fast path without a spare V^T row: every row accumulates sum_k P (ones-operand MFMA)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Lacc[r] = 0.f;
     // Running max m (log2 units) enters the scores through ONE extra QK^T MFMA k-step instead of
     // 16 VALU subtractions per block: K is extended by constant columns [1, 1, mask] and Q by
     // [-m_hi, -m_lo, -BIG] (m split in two bf16 terms, exact in the fp32 accumulate), so the MFMA
@@ -259,6 +263,69 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
         }
     };
 
+    // ---- bf16 fast path: a-priori softmax shift.  |c*q.k| <= |c*q| * max_k|k| =: ub (Cauchy-Schwarz on the exact
+    // bf16 operands), so m = ub is a valid shift for EVERY key: no running max, no rescale, no extra MFMA k-step --
+    // the shift enters as the MFMA's C operand.  exp2 arguments lie in [-2ub, 0]; with ub <= 60 nothing leaves the
+    // normal fp32/bf16 range, so the result is as accurate as the online-max form.  Waves with a larger bound
+    // (wave-uniform test) take the online-max loop below.
+    bool fast = false;
+    f32x16 negm;
+    if constexpr (BF) {
+        if (p.kmax2) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float t = (float)qf[ks][j]; q2 = fmaf(t, t, q2); }
+            unsigned u = __float_as_uint(q2);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            const float ub = sqrtf(q2 * p.kmax2[b * p.heads + head]) * 1.002f + 1e-3f;
+            fast = __all(ub <= 60.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -ub;
+        }
+    }
+    // one 32-key block of the fast path; TAIL: keys >= n contribute exp2 -> 0 explicitly
+    auto block_fast = [&](const int kb, const int buf, const int k0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if constexpr (BF) {
+            f32x16 s = negm;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][kb * 32 * KSTR + kbase + 16 * ks]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pr[r] = key < n ? pr[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
+#pragma unroll
+                for (int g = 0; g < DG; ++g) {
+                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][g * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
+                    O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
+                }
+                if constexpr (!SUMROW) {  // no spare V^T row: the denominators come from a constant all-ones A operand
+                    bf16x8 ones;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
+                    Lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, Lacc, 0, 0, 0);
+                }
+            }
+        }
+    };
+
     const int ntiles = (n + KT - 1) / KT;
     __syncthreads();
     if constexpr (SUMROW) {  // ones row (after the zero fill, before the first tile lands)
@@ -268,14 +335,31 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     store_tile(0);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile((t + 1) * KT);
-        const int k0 = t * KT;
-        block(0, buf, k0);
-        if (k0 + 32 < n) block(1, buf, k0);
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
+    if (fast) {
+        for (int t = 0; t < ntiles; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntiles) load_tile((t + 1) * KT);
+            const int k0 = t * KT;
+            if (k0 + KT <= n) {
+                block_fast(0, buf, k0, std::false_type{});
+                block_fast(1, buf, k0, std::false_type{});
+            } else {
+                block_fast(0, buf, k0, std::true_type{});
+                if (k0 + 32 < n) block_fast(1, buf, k0, std::true_type{});
+            }
+            if (t + 1 < ntiles) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntiles) load_tile((t + 1) * KT);
+            const int k0 = t * KT;
+            block(0, buf, k0);
+            if (k0 + 32 < n) block(1, buf, k0);
+            if (t + 1 < ntiles) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- finish: denominators (ones-row or summed halves), normalise, store
@@ -284,6 +368,8 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
         unsigned u = __float_as_uint(O[DG - 1][rl]);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         l_run = __uint_as_float(sw[hl]);
+    } else if (fast) {
+        l_run = Lacc[0];  // every row of Lacc holds sum_k P[k][q] for this lane's query
     } else {
         unsigned u = __float_as_uint(l_run);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -308,6 +394,28 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     }
 }
 
+// max over the keys of one (b, head) of |k|^2, for the fast path's score bound.  grid (chunks, heads, B); positive
+// floats order like their bit patterns, so the cross-block max is an integer atomicMax on a zeroed word.
+#define KMAX_ROWS 2048
+__global__ void __launch_bounds__(256) attn_kmax_kernel(const bf16_t* __restrict__ k, int ldk, int n, int heads, int hd,
+                                                        unsigned* __restrict__ out) {
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int r0 = blockIdx.x * KMAX_ROWS, r1 = min(n, r0 + KMAX_ROWS);
+    float m = 0.f;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const bf16_t* kr = k + ((size_t)b * n + r) * ldk + (size_t)head * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            float4 v = load4(kr + d);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+        m = fmaxf(m, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + b * heads + head, __float_as_uint(m));
+}
+
 template <typename T, int HD>
 static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
     dim3 grid(ceil_div(p.n, 128), p.heads, B);
@@ -324,9 +432,12 @@ static int launch_attn(const AttnP& p, int nv, int B, hipStream_t stream) {
     return launch_attn_nv<T, 64>(p, nv, B, stream);
 }
 
+extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int heads) { return (size_t)B * heads * sizeof(float); }
+
 extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1,
                                const void* v2, int ldv2, int dtype, int B, int n, int heads, int hd, float scale,
-                               void* o1, int ldo1, void* o2, int ldo2, int out_dtype, uwir_stream_t stream) {
+                               void* o1, int ldo1, void* o2, int ldo2, int out_dtype, void* workspace,
+                               size_t workspace_bytes, uwir_stream_t stream) {
     UWIR_CHECK(q && k && v1 && o1, "flash_attn: null pointer");
     UWIR_CHECK((v2 == nullptr) == (o2 == nullptr), "flash_attn: v2 and o2 must come together");
     UWIR_CHECK(B > 0 && B <= 65535 && heads > 0 && heads <= 65535 && n > 0, "flash_attn: bad shape");
@@ -350,6 +461,18 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     UWIR_CHECK(scale >= 0.f, "flash_attn: negative scale");
     p.c = scale == 0.f ? 1.f : scale * 1.4426950408889634f;
     int nv = v2 ? 2 : 1;
+    p.kmax2 = nullptr;
+    if (dtype == UWIR_BF16 && workspace) {
+        UWIR_CHECK(workspace_bytes >= uwir_flash_attn_workspace_bytes(B, heads) && ((uintptr_t)workspace & 3) == 0,
+                   "flash_attn: workspace too small / misaligned");
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemsetAsync(workspace, 0, (size_t)B * heads * sizeof(float), s) != hipSuccess)
+            return uwir_set_error(UWIR_ELAUNCH, "flash_attn: hipMemsetAsync failed");
+        hipLaunchKernelGGL(attn_kmax_kernel, dim3(ceil_div(n, KMAX_ROWS), heads, B), dim3(256), 0, s, (const bf16_t*)k, ldk,
+                           n, heads, hd, (unsigned*)workspace);
+        UWIR_LAUNCH_CHECK("flash_attn(kmax)");
+        p.kmax2 = (const float*)workspace;
+    }
     if (dtype == UWIR_BF16) return launch_attn<bf16_t>(p, nv, B, (hipStream_t)stream);
     return launch_attn<float>(p, nv, B, (hipStream_t)stream);
 }
