@@ -133,10 +133,11 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 64.
  * scale = 1/sqrt(hd) normally; scale == 0 means "q is already multiplied by (1/sqrt(hd))*log2(e)" (the producing
  * GEMM applied it through col_scale), which saves one bf16 rounding of q.
- * workspace (optional, >= uwir_flash_attn_workspace_bytes(B, heads), 4-byte aligned): enables the bf16 fast path --
- * a pre-pass stores max_k |k|^2 per (b, head) there and the softmax shift becomes the a-priori bound
- * |c q| * max|k| (no running max / rescale); waves whose bound exceeds 60 (log2 units) use the online-max loop. */
-size_t uwir_flash_attn_workspace_bytes(int B, int heads);
+ * workspace (optional, >= uwir_flash_attn_workspace_bytes(B, n, heads), 4-byte aligned): enables the bf16 fast path --
+ * a pre-pass stores max_k |k|^2 per (b, head) there; where the a-priori score bound |c q| * max|k| is <= 60 (log2
+ * units) exp2 cannot leave the fp32/bf16 range, the (mathematically cancelling) softmax shift is dropped and no
+ * running max / rescale is computed; blocks with a larger bound run the online-max loop. */
+size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads);
 int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1, const void* v2,
                     int ldv2, int dtype, int B, int n, int heads, int hd, float scale, void* o1, int ldo1,
                     void* o2, int ldo2, int out_dtype, void* workspace, size_t workspace_bytes, uwir_stream_t stream);

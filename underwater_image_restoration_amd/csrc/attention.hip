@@ -20,6 +20,7 @@ struct AttnP {
     int n, heads, hd, out_dtype;
     float c;  // scale * log2(e); 1 when q is pre-scaled
     const float* kmax2;  // optional [B*heads]: max over keys of |k|^2 (bf16 fast path: a-priori score bound)
+    int* flags;          // split launch: per-block "bound too large, redo with the online-max kernel" marks
 };
 
 #define AT_KT 64
@@ -28,9 +29,21 @@ template <typename T> struct Chunk4;
 template <> struct Chunk4<bf16_t> { typedef bf16x4 type; };
 template <> struct Chunk4<float> { typedef f32x4 type; };
 
-template <typename T, int HD, int NV>
+template <int G> struct GIdx { static constexpr int value = G; };
+
+// QG = 32-query groups per wave (1 or 2).  With 2, every staged K / V^T tile and every LDS fragment read feeds two
+// independent S^T / O^T chains: the per-tile staging + barrier cost per (query, key) pair halves and each wave has
+// two dependency chains to interleave.  Block = 4 waves x 32*QG queries.
+// MODE 0: one launch holding both loops (per-wave choice).  Split launch for the big problems, so that the hot
+// kernel carries only the fast loop's registers: MODE 1 = fast loop only, a block whose bound is too large marks
+// itself in p.flags and leaves; MODE 2 = online-max loop only, run by the marked blocks (all others exit at once).
+template <typename T, int HD, int NV, int QG, int MODE>
 __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     constexpr bool BF = sizeof(T) == 2;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if constexpr (MODE == 2) {
+        if (p.flags[blk] == 0) return;  // block-uniform, ahead of every barrier
+    }
     constexpr int KT = AT_KT;
     constexpr int KSTR = HD + (BF ? 8 : 1);   // sK row stride (elements)
     constexpr int VSTR = KT + (BF ? 8 : 1);   // sVt row stride
@@ -51,7 +64,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     const int head = blockIdx.y, b = blockIdx.z;
     const int n = p.n, hd = p.hd;
     const size_t row0 = (size_t)b * n;
-    const int q_idx = blockIdx.x * 128 + wave * 32 + lq;  // this lane's query
+    const int qbase = blockIdx.x * (128 * QG) + wave * (32 * QG) + lq;  // this lane's query in group g: qbase + 32 g
     const float c = p.c;
 
     const T* __restrict__ Kp = (const T*)p.k + (size_t)head * hd;
@@ -66,9 +79,11 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     //      yields scores directly in the log2 domain and exp2 needs no per-element multiply.
     constexpr int KS = BF ? HD / 16 : HD / 2;
     typedef typename std::conditional<BF, bf16x8, float>::type QF;
-    QF qf[KS];
-    {
+    QF qf[QG][KS];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
         const T* Qp = (const T*)p.q + (size_t)head * hd;
+        const int q_idx = qbase + 32 * g;
         const bool qok = q_idx < n;
         const T* qrow = Qp + (row0 + (qok ? q_idx : 0)) * p.ldq;
         if constexpr (BF) {
@@ -84,28 +99,28 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) f[4 * half + e] = c == 1.f ? v[e] : (bf16_t)((float)v[e] * c);
                 }
-                qf[ks] = f;
+                qf[g][ks] = f;
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 int d = 2 * ks + lh;
-                qf[ks] = (qok && d < hd) ? (float)qrow[d] * c : 0.f;
+                qf[g][ks] = (qok && d < hd) ? (float)qrow[d] * c : 0.f;
             }
         }
     }
 
-    // ---- staging registers
+    // ---- staging registers.  Rows past n are CLAMPED to the last key, not zero-filled: every consumer masks keys
+    //      >= n itself (P = 0 there), and a real row is finite, so no predicate / zero-fill sits in the loop.
     C4 rk[NKC], rv[NV][NKC];
     auto zero4 = [](C4& v) { v[0] = (T)0.f; v[1] = (T)0.f; v[2] = (T)0.f; v[3] = (T)0.f; };
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NKC; ++i) {
             int cidx = tid + 256 * i;
-            int key = k0 + cidx / QPR, d = 4 * (cidx % QPR);
-            bool ok = key < n && d < hd;
-            size_t r = row0 + (ok ? key : 0);
-            if (ok) {
+            int key = min(k0 + cidx / QPR, n - 1), d = 4 * (cidx % QPR);
+            size_t r = row0 + key;
+            if (HD == hd || d < hd) {
                 rk[i] = *reinterpret_cast<const C4*>(Kp + r * p.ldk + d);
                 rv[0][i] = *reinterpret_cast<const C4*>(Vp0 + r * p.ldv[0] + d);
                 if constexpr (NV > 1) rv[1][i] = *reinterpret_cast<const C4*>(Vp1 + r * p.ldv[1] + d);
@@ -139,34 +154,44 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
         }
     };
 
-    f32x16 O[DG];
+    f32x16 O[QG][DG];
 #pragma unroll
-    for (int g = 0; g < DG; ++g)
+    for (int g = 0; g < QG; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[g][r] = 0.f;
-    f32x16 Lacc;  // fast path without a spare V^T row: every row accumulates sum_k P (ones-operand MFMA)
+        for (int dg = 0; dg < DG; ++dg)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Lacc[r] = 0.f;
-    // Running max m (log2 units) enters the scores through ONE extra QK^T MFMA k-step instead of
-    // 16 VALU subtractions per block: K is extended by constant columns [1, 1, mask] and Q by
+            for (int r = 0; r < 16; ++r) O[g][dg][r] = 0.f;
+    f32x16 Lacc[QG];  // fast path without a spare V^T row: every row accumulates sum_k P (ones-operand MFMA)
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Lacc[g][r] = 0.f;
+    // Online-max loop: the running max m (log2 units) enters the scores through ONE extra QK^T MFMA k-step instead
+    // of 16 VALU subtractions per block: K is extended by constant columns [1, 1, mask] and Q by
     // [-m_hi, -m_lo, -BIG] (m split in two bf16 terms, exact in the fp32 accumulate), so the MFMA
     // emits c*S - m directly, keys >= n are pushed to -BIG (exp2 -> 0) and the numerator is a bare exp2.
-    float m_eff = 0.f;
-    QF qext;
-    if constexpr (BF) {
+    float m_eff[QG], l_run[QG];
+    bool first[QG];        // the first block adopts its own max unconditionally (wave-uniform)
+    QF qext[QG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qext[j] = (bf16_t)0.f;
-        qext[2] = (bf16_t)(-30000.f);
-    } else {
-        qext = lh == 0 ? 0.f : -1e30f;
+    for (int g = 0; g < QG; ++g) {
+        m_eff[g] = 0.f;
+        l_run[g] = 0.f;    // this lane's partial denominator (unused when the ones-row provides it)
+        first[g] = true;
+        if constexpr (BF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qext[g][j] = (bf16_t)0.f;
+            qext[g][2] = (bf16_t)(-30000.f);
+        } else {
+            qext[g] = lh == 0 ? 0.f : -1e30f;
+        }
     }
-    float l_run = 0.f;     // this lane's partial denominator (unused when the ones-row provides it)
-    bool first = true;     // the first block adopts its own max unconditionally (wave-uniform)
     constexpr float THR = BF ? 4.f : 0.f;
     const int kbase = lq * KSTR + (BF ? 8 : 1) * lh;
     const int vbase = lq * VSTR + (BF ? 8 * lh : 0);
 
-    auto block = [&](const int kb, const int buf, const int k0) {
+    auto block = [&](const int kb, const int buf, const int k0, auto gtag) {
+        constexpr int g = decltype(gtag)::value;
         const bool masked = (k0 + kb * 32 + lq) >= n;
         // ---- S^T = K . Q^T - m
         f32x16 s;
@@ -176,7 +201,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][kb * 32 * KSTR + kbase + 16 * ks]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[g][ks], s, 0, 0, 0);
             }
             bf16x8 kext;
             const bf16_t one = (bf16_t)(lh == 0 ? 1.f : 0.f);
@@ -185,15 +210,15 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             kext[0] = one;
             kext[1] = one;
             kext[2] = (bf16_t)((lh == 0 && masked) ? 1.f : 0.f);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kext, qext, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kext, qext[g], s, 0, 0, 0);
         } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float kf = sK[buf][kb * 32 * KSTR + kbase + 2 * ks];
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[g][ks], s, 0, 0, 0);
             }
             const float kext = lh == 0 ? 1.f : (masked ? 1.f : 0.f);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kext, qext, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kext, qext[g], s, 0, 0, 0);
         }
         // ---- online softmax, deferred max: rescale only when the block max exceeds the running max by > THR
         float mxa = fmaxf(s[0], s[1]);
@@ -204,29 +229,29 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mxa = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        if (first || __any(mxa > THR)) {
-            const float delta = first ? mxa : fmaxf(mxa, 0.f);
-            float m_new = m_eff + delta;
+        if (first[g] || __any(mxa > THR)) {
+            const float delta = first[g] ? mxa : fmaxf(mxa, 0.f);
+            float m_new = m_eff[g] + delta;
             if constexpr (BF) {
                 const bf16_t hi = (bf16_t)m_new;
                 const bf16_t lo = (bf16_t)(m_new - (float)hi);
                 m_new = (float)hi + (float)lo;  // exactly what the next MFMA will subtract
-                qext[0] = (bf16_t)(-(float)hi);
-                qext[1] = (bf16_t)(-(float)lo);
+                qext[g][0] = (bf16_t)(-(float)hi);
+                qext[g][1] = (bf16_t)(-(float)lo);
             } else {
-                if (lh == 0) qext = -m_new;
+                if (lh == 0) qext[g] = -m_new;
             }
-            const float dlt = m_new - m_eff;
-            m_eff = m_new;
-            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-dlt);
-            first = false;
+            const float dlt = m_new - m_eff[g];
+            m_eff[g] = m_new;
+            const float alpha = first[g] ? 1.f : __builtin_amdgcn_exp2f(-dlt);
+            first[g] = false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] -= dlt;
-            l_run *= alpha;
+            l_run[g] *= alpha;
 #pragma unroll
-            for (int g = 0; g < DG; ++g)
+            for (int dg = 0; dg < DG; ++dg)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) O[g][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[g][dg][r] *= alpha;
         }
         float pr[16];
 #pragma unroll
@@ -235,7 +260,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             float l0 = 0.f, l1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { l0 += pr[r]; l1 += pr[r + 1]; }
-            l_run += l0 + l1;
+            l_run[g] += l0 + l1;
         }
         // ---- O^T += V^T . P   (with SUMROW, row DV of V^T is all ones, so O^T[DV][q] accumulates sum_k P)
         if constexpr (BF) {
@@ -245,9 +270,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
 #pragma unroll
-                for (int g = 0; g < DG; ++g) {
-                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][g * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
-                    O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
+                for (int dg = 0; dg < DG; ++dg) {
+                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][dg * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
+                    O[g][dg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g][dg], 0, 0, 0);
                 }
             }
         } else {
@@ -255,72 +280,98 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
-                for (int g = 0; g < DG; ++g) {
-                    float vf = sVt[buf][g * 32 * VSTR + vbase + key];
-                    O[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], O[g], 0, 0, 0);
+                for (int dg = 0; dg < DG; ++dg) {
+                    float vf = sVt[buf][dg * 32 * VSTR + vbase + key];
+                    O[g][dg] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], O[g][dg], 0, 0, 0);
                 }
             }
         }
     };
 
-    // ---- bf16 fast path: a-priori softmax shift.  |c*q.k| <= |c*q| * max_k|k| =: ub (Cauchy-Schwarz on the exact
-    // bf16 operands), so m = ub is a valid shift for EVERY key: no running max, no rescale, no extra MFMA k-step --
-    // the shift enters as the MFMA's C operand.  exp2 arguments lie in [-2ub, 0]; with ub <= 60 nothing leaves the
-    // normal fp32/bf16 range, so the result is as accurate as the online-max form.  Waves with a larger bound
-    // (wave-uniform test) take the online-max loop below.
+    // ---- bf16 fast path: a-priori score bound.  |c*q.k| <= |c*q| * max_k|k| =: ub (Cauchy-Schwarz on the exact bf16
+    // operands).  The softmax shift is a per-query constant that cancels in O / l, so it only has to keep exp2 in
+    // range: with ub <= 60 every exp2 argument lies in [-60, 60], P (bf16, 8-bit exponent) and the fp32 sums
+    // (<= n * 2^60) stay normal, and NO shift is applied at all -- no running max, no rescale, no extra MFMA k-step,
+    // same relative accuracy as the online-max form.  Waves with a larger bound (wave-uniform test) take the
+    // online-max loop; both loops stage the same tiles behind the same barriers.
     bool fast = false;
-    f32x16 negm;
-    if constexpr (BF) {
-        if (p.kmax2) {
-            float q2 = 0.f;
+    if constexpr (BF && MODE != 2) {
+        if (MODE == 1 || p.kmax2) {
+            bool ok = true;
+            const float km2 = p.kmax2[b * p.heads + head];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int g = 0; g < QG; ++g) {
+                float q2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float t = (float)qf[ks][j]; q2 = fmaf(t, t, q2); }
-            unsigned u = __float_as_uint(q2);
-            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-            const float ub = sqrtf(q2 * p.kmax2[b * p.heads + head]) * 1.002f + 1e-3f;
-            fast = __all(ub <= 60.f);
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] = -ub;
+                    for (int j = 0; j < 8; ++j) { float t = (float)qf[g][ks][j]; q2 = fmaf(t, t, q2); }
+                unsigned u = __float_as_uint(q2);
+                auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                const float ub = sqrtf(q2 * km2) * 1.002f + 1e-3f;
+                ok = ok && ub <= 60.f;
+            }
+            if constexpr (MODE == 1) {
+                if (__syncthreads_or(!ok)) {  // block-uniform: leave the whole block to the online-max launch
+                    if (tid == 0) p.flags[blk] = 1;
+                    return;
+                }
+                fast = true;
+            } else {
+                fast = __all(ok);
+            }
         }
     }
-    // one 32-key block of the fast path; TAIL: keys >= n contribute exp2 -> 0 explicitly
+    // one 32-key block of the fast path for all QG query groups; TAIL: keys >= n get P = 0 explicitly
     auto block_fast = [&](const int kb, const int buf, const int k0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         if constexpr (BF) {
-            f32x16 s = negm;
+            f32x16 s[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[g][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][kb * 32 * KSTR + kbase + 16 * ks]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[g][ks], s[g], 0, 0, 0);
             }
-            float pr[16];
+            bf16x8 pb[QG][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
-            if constexpr (TAIL) {
+            for (int g = 0; g < QG; ++g) {
+                float pr[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    pr[r] = key < n ? pr[r] : 0.f;
+                for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[g][r]);
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        pr[r] = key < n ? pr[r] : 0.f;
+                    }
                 }
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[g][ss][j] = (bf16_t)pr[8 * ss + j];
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                bf16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)pr[8 * ss + j];
+                for (int dg = 0; dg < DG; ++dg) {
+                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][dg * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
 #pragma unroll
-                for (int g = 0; g < DG; ++g) {
-                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[buf][g * 32 * VSTR + vbase + kb * 32 + 16 * ss]);
-                    O[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[g], 0, 0, 0);
+                    for (int g = 0; g < QG; ++g)
+                        O[g][dg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[g][ss], O[g][dg], 0, 0, 0);
                 }
                 if constexpr (!SUMROW) {  // no spare V^T row: the denominators come from a constant all-ones A operand
                     bf16x8 ones;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
-                    Lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, Lacc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g)
+                        Lacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[g][ss], Lacc[g], 0, 0, 0);
                 }
             }
         }
@@ -335,7 +386,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     store_tile(0);
     __syncthreads();
 
-    if (fast) {
+    if (MODE == 1 || (MODE == 0 && fast)) {
         for (int t = 0; t < ntiles; ++t) {
             const int buf = t & 1;
             if (t + 1 < ntiles) load_tile((t + 1) * KT);
@@ -350,45 +401,54 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             if (t + 1 < ntiles) store_tile(buf ^ 1);
             __syncthreads();
         }
-    } else {
+    } else if constexpr (MODE != 1) {
         for (int t = 0; t < ntiles; ++t) {
             const int buf = t & 1;
             if (t + 1 < ntiles) load_tile((t + 1) * KT);
             const int k0 = t * KT;
-            block(0, buf, k0);
-            if (k0 + 32 < n) block(1, buf, k0);
+            block(0, buf, k0, GIdx<0>{});
+            if constexpr (QG > 1) block(0, buf, k0, GIdx<QG - 1>{});
+            if (k0 + 32 < n) {
+                block(1, buf, k0, GIdx<0>{});
+                if constexpr (QG > 1) block(1, buf, k0, GIdx<QG - 1>{});
+            }
             if (t + 1 < ntiles) store_tile(buf ^ 1);
             __syncthreads();
         }
     }
 
-    // ---- finish: denominators (ones-row or summed halves), normalise, store
-    if constexpr (SUMROW) {
-        constexpr int lr = DV % 32, rl = (lr & 3) + 4 * (lr >> 3), hl = (lr >> 2) & 1;
-        unsigned u = __float_as_uint(O[DG - 1][rl]);
-        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        l_run = __uint_as_float(sw[hl]);
-    } else if (fast) {
-        l_run = Lacc[0];  // every row of Lacc holds sum_k P[k][q] for this lane's query
-    } else {
-        unsigned u = __float_as_uint(l_run);
-        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    if (q_idx >= n) return;
-    const float inv = 1.f / l_run;
+    // ---- finish: denominators (ones-row, ones-operand accumulator or summed halves), normalise, store
 #pragma unroll
-    for (int g = 0; g < DG; ++g) {
+    for (int g = 0; g < QG; ++g) {
+        float l;
+        if constexpr (SUMROW) {
+            constexpr int lr = DV % 32, rl = (lr & 3) + 4 * (lr >> 3), hl = (lr >> 2) & 1;
+            unsigned u = __float_as_uint(O[g][DG - 1][rl]);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            l = __uint_as_float(sw[hl]);
+        } else if (MODE != 2 && fast) {
+            l = Lacc[g][0];  // every row of Lacc holds sum_k P[k][q] for this lane's query
+        } else {
+            unsigned u = __float_as_uint(l_run[g]);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const int q_idx = qbase + 32 * g;
+        if (q_idx >= n) continue;
+        const float inv = 1.f / l;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int d = g * 32 + 8 * rq + 4 * lh;  // rows d..d+3 live in regs 4*rq..4*rq+3
-            const int v = d / HD, dd = d % HD;
-            if (v < NV && dd < hd) {
-                float4 o = make_float4(O[g][4 * rq] * inv, O[g][4 * rq + 1] * inv, O[g][4 * rq + 2] * inv,
-                                       O[g][4 * rq + 3] * inv);
-                size_t off = (row0 + q_idx) * p.ldo[v] + (size_t)head * hd + dd;
-                if (p.out_dtype == UWIR_F32) store4((float*)p.o[v] + off, o);
-                else store4((bf16_t*)p.o[v] + off, o);
+        for (int dg = 0; dg < DG; ++dg) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dg * 32 + 8 * rq + 4 * lh;  // rows d..d+3 live in regs 4*rq..4*rq+3
+                const int v = d / HD, dd = d % HD;
+                if (v < NV && dd < hd) {
+                    float4 o = make_float4(O[g][dg][4 * rq] * inv, O[g][dg][4 * rq + 1] * inv, O[g][dg][4 * rq + 2] * inv,
+                                           O[g][dg][4 * rq + 3] * inv);
+                    size_t off = (row0 + q_idx) * p.ldo[v] + (size_t)head * hd + dd;
+                    if (p.out_dtype == UWIR_F32) store4((float*)p.o[v] + off, o);
+                    else store4((bf16_t*)p.o[v] + off, o);
+                }
             }
         }
     }
@@ -418,9 +478,20 @@ __global__ void __launch_bounds__(256) attn_kmax_kernel(const bf16_t* __restrict
 
 template <typename T, int HD>
 static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
+    // big bf16 problems with hd <= 16: two query groups per wave (256 queries per block) and the split launch
+    if constexpr (sizeof(T) == 2 && HD <= 16) {
+        // (the two-V variant measured no faster this way -- 202 VGPRs, 2 waves/SIMD -- and stays on the single launch)
+        if (nv == 1 && p.flags && (long long)ceil_div(p.n, 256) * p.heads * B >= 1024) {
+            dim3 grid(ceil_div(p.n, 256), p.heads, B);
+            hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 2, 1>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 2, 2>), grid, dim3(256), 0, stream, p);
+            UWIR_LAUNCH_CHECK("flash_attn(split)");
+            return UWIR_OK;
+        }
+    }
     dim3 grid(ceil_div(p.n, 128), p.heads, B);
-    if (nv == 1) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2>), grid, dim3(256), 0, stream, p);
+    if (nv == 1) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 1, 0>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2, 1, 0>), grid, dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("flash_attn");
     return UWIR_OK;
 }
@@ -432,7 +503,11 @@ static int launch_attn(const AttnP& p, int nv, int B, hipStream_t stream) {
     return launch_attn_nv<T, 64>(p, nv, B, stream);
 }
 
-extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int heads) { return (size_t)B * heads * sizeof(float); }
+// [B*heads] floats (max |k|^2) followed by one int per 256-query block (split-launch marks)
+static size_t attn_ws_bytes(int B, int n, int heads) {
+    return ((size_t)B * heads + (size_t)ceil_div(n, 256) * heads * B) * sizeof(float);
+}
+extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads) { return attn_ws_bytes(B, n, heads); }
 
 extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1,
                                const void* v2, int ldv2, int dtype, int B, int n, int heads, int hd, float scale,
@@ -462,16 +537,18 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     p.c = scale == 0.f ? 1.f : scale * 1.4426950408889634f;
     int nv = v2 ? 2 : 1;
     p.kmax2 = nullptr;
+    p.flags = nullptr;
     if (dtype == UWIR_BF16 && workspace) {
-        UWIR_CHECK(workspace_bytes >= uwir_flash_attn_workspace_bytes(B, heads) && ((uintptr_t)workspace & 3) == 0,
+        UWIR_CHECK(workspace_bytes >= attn_ws_bytes(B, n, heads) && ((uintptr_t)workspace & 3) == 0,
                    "flash_attn: workspace too small / misaligned");
         hipStream_t s = (hipStream_t)stream;
-        if (hipMemsetAsync(workspace, 0, (size_t)B * heads * sizeof(float), s) != hipSuccess)
+        if (hipMemsetAsync(workspace, 0, attn_ws_bytes(B, n, heads), s) != hipSuccess)
             return uwir_set_error(UWIR_ELAUNCH, "flash_attn: hipMemsetAsync failed");
         hipLaunchKernelGGL(attn_kmax_kernel, dim3(ceil_div(n, KMAX_ROWS), heads, B), dim3(256), 0, s, (const bf16_t*)k, ldk,
                            n, heads, hd, (unsigned*)workspace);
         UWIR_LAUNCH_CHECK("flash_attn(kmax)");
         p.kmax2 = (const float*)workspace;
+        p.flags = (int*)workspace + (size_t)B * heads;
     }
     if (dtype == UWIR_BF16) return launch_attn<bf16_t>(p, nv, B, (hipStream_t)stream);
     return launch_attn<float>(p, nv, B, (hipStream_t)stream);

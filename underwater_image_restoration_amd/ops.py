@@ -156,9 +156,9 @@ def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, ou
 _ATTN_WS = {}
 
 
-def _attn_workspace(dev, B: int, heads: int) -> torch.Tensor:
-    """Small per-device scratch for the bf16 fast path (max_k |k|^2 per (b, head)); grown on demand, reused."""
-    need = int(_lib.load().uwir_flash_attn_workspace_bytes(B, heads))
+def _attn_workspace(dev, B: int, n: int, heads: int) -> torch.Tensor:
+    """Small per-device scratch for the bf16 fast path (max_k |k|^2 per (b, head) + block marks); grown on demand."""
+    need = int(_lib.load().uwir_flash_attn_workspace_bytes(B, n, heads))
     t = _ATTN_WS.get(dev)
     if t is None or t.numel() * 4 < need:
         t = torch.empty(max(need // 4, 4096), dtype=torch.float32, device=dev)
@@ -177,7 +177,7 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    ws = _attn_workspace(q.device, B, heads) if (fast and dt == BF16) else None
+    ws = _attn_workspace(q.device, B, n, heads) if (fast and dt == BF16) else None
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
                                    0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
                                    0 if o2 is None else _ld(o2), _dt(o1), _p(ws), 0 if ws is None else ws.numel() * 4,
