@@ -176,13 +176,18 @@ def main() -> None:
         n0 = (args.size // 2) ** 2
         dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
         roof = None
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
+        if os.path.exists(tj) and args.batch == 16 and args.size == 256 and args.precision == "bf16":
+            with open(tj) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         if dom:
             avg_ms = sum(dom) / len(dom)
             fl = 4.0 * args.batch * 12 * float(n0) ** 2 * (args.size and 16)  # 4*B*heads*n^2*hd
             ach = fl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            roof = {"bound": "mfma", "kernel": "flash_attn_kernel<hd16,1V> (WTB level 0)", "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            roof = {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd16,1V> (WTB level 0; kmax pre-pass + fast + online-max launches)", "achieved": round(ach, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}
         cpu = None
         if args.cpu_baseline != "skip" and world == 1 and args.workload == "student":
