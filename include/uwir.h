@@ -60,6 +60,11 @@ int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, co
                      const float* scale_shift, int ss_ld, float* a_out, float* s_out, float* mean_out,
                      float* pooled_out, void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
+/* ---- materialised form of the same norm (S/utils.py:18-36): out[m,c] = a[b,c]*x[m,c] + s[b,c], b = m / n, out fp32
+ * or bf16.  For consumers that are better fed a ready bf16 operand (LDS-DMA GEMM path) than normalise-on-load. */
+int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
+                     int out_dtype, int ldo, uwir_stream_t stream);
+
 /* ---- S/wtb.py:13-28,118-119 ChannelAttention folded into the residual ------------------------
  * With xn = a*x + s (the affine above) and w = sigmoid(MLP(mean(xn))) [B,C]:
  *   x + xn*w == x*(1 + a*w) + s*w   ->  out_scale = 1 + a*w, out_shift = s*w   (count = B*C).

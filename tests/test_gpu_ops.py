@@ -525,3 +525,14 @@ def test_flash_attn_bf16_fast_path_and_fallback(ops, cfg):
         if not expect_fast:  # bound > 60 everywhere: the fast call must have taken the very same online-max code
             for a_, b_ in zip(outs[True], outs[False]):
                 assert torch.equal(a_, b_)
+
+
+def test_affine_cast(ops):
+    g = torch.Generator().manual_seed(20)
+    b, n, c = 3, 37, 24
+    x, a, s = torch.randn(b * n, c + 4, generator=g), torch.randn(b, c, generator=g), torch.randn(b, c, generator=g)
+    ref = x[:, :c].reshape(b, n, c).double() * a.double()[:, None] + s.double()[:, None]
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        out = torch.full((b * n, c + 8), 4.0, device="cuda", dtype=dt)
+        ops.affine_cast(x.cuda()[:, :c], b, n, c, a.cuda(), s.cuda(), out[:, :c])
+        assert err(out[:, :c].reshape(b, n, c), ref) < tol and float(out[:, c:].float().min()) == 4.0

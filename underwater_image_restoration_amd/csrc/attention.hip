@@ -387,8 +387,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     __syncthreads();
 
     if (MODE == 1 || (MODE == 0 && fast)) {
-        for (int t = 0; t < ntiles; ++t) {
-            const int buf = t & 1;
+        // two tiles per trip with compile-time buffer indices: halves the loop-carried accumulator copies the
+        // register allocator leaves at the back edge and folds the LDS buffer offsets into immediates
+        auto tile_fast = [&](const int t, const int buf) {
             if (t + 1 < ntiles) load_tile((t + 1) * KT);
             const int k0 = t * KT;
             if (k0 + KT <= n) {
@@ -400,7 +401,13 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             }
             if (t + 1 < ntiles) store_tile(buf ^ 1);
             __syncthreads();
+        };
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            tile_fast(t, 0);
+            tile_fast(t + 1, 1);
         }
+        if (t < ntiles) tile_fast(t, 0);
     } else if constexpr (MODE != 1) {
         for (int t = 0; t < ntiles; ++t) {
             const int buf = t & 1;

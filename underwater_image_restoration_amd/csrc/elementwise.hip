@@ -243,6 +243,43 @@ extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, fl
 }
 
 // ------------------------------------------------------------------------------------------
+// Apply a folded per-(b,c) norm affine and cast: out[m,c] = a[b,c]*x[m,c] + s[b,c] (bf16 or fp32 out).
+// Used where the consumer GEMM is better fed by the LDS-DMA bf16 path than by normalise-on-load:
+// one extra HBM pass (6 B / element) buys the 16-byte DMA pipeline for the whole GEMM.
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void __launch_bounds__(256) affine_cast_kernel(const float* __restrict__ x, int ldx, int n, int C4,
+                                                          const float* __restrict__ a, const float* __restrict__ sh,
+                                                          TO* __restrict__ out, int ldo, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t m = i / C4;
+        int b = (int)(m / n);
+        float4 v = load4(x + m * ldx + 4 * c4);
+        float4 sc = load4(a + ((size_t)b * C4 + c4) * 4), h = load4(sh + ((size_t)b * C4 + c4) * 4);
+        store4(out + m * ldo + 4 * c4,
+               make_float4(fmaf(v.x, sc.x, h.x), fmaf(v.y, sc.y, h.y), fmaf(v.z, sc.z, h.z), fmaf(v.w, sc.w, h.w)));
+    }
+}
+
+extern "C" int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
+                                int out_dtype, int ldo, uwir_stream_t stream) {
+    UWIR_CHECK(x && a && s && out, "affine_cast: null pointer");
+    UWIR_CHECK(B > 0 && n > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && ldo >= C && ldo % 4 == 0,
+               "affine_cast: bad shape");
+    UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "affine_cast: bad output dtype");
+    size_t total = (size_t)B * n * (C / 4);
+    if (out_dtype == UWIR_F32)
+        hipLaunchKernelGGL(affine_cast_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
+                           C / 4, a, s, (float*)out, ldo, total);
+    else
+        hipLaunchKernelGGL(affine_cast_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
+                           C / 4, a, s, (bf16_t*)out, ldo, total);
+    UWIR_LAUNCH_CHECK("affine_cast");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm (U/models/modules/attention.py:76-77,236,254: 32 groups, eps 1e-6, affine) as a folded
 // per-(b,c) affine a*x + s for the consumer GEMM's normalise-on-load.  Statistics: the per-channel
 // shifted partial sums of ln_partial_kernel, merged per group in fp64 (parallel-variance formula).

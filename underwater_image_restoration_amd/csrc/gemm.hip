@@ -154,15 +154,31 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     int ra_c[ACH];
     RawChunk<TC, EPC> rb[BCH];
 
+    // k -> (tap, channel): when C % BK == 0 a whole K tile lies inside ONE filter tap, so the two integer divisions
+    // are wave-uniform scalar work done once per tile instead of per chunk on the vector ALU (the im2col address
+    // arithmetic used to outweigh the tile's 32 MFMAs for k x k convs).
+    const bool tap_uniform = !is1x1 && (C % BK == 0);
     auto load_regs = [&](int kt) {
+        int tap_s = 0, ky_s = 0, kx_s = 0, ch_s = 0;
+        if (tap_uniform) {
+            const int k0 = kt * BK;
+            tap_s = __builtin_amdgcn_readfirstlane(k0 / C);
+            ch_s = k0 - tap_s * C;
+            ky_s = __builtin_amdgcn_readfirstlane(tap_s / g.KW);
+            kx_s = tap_s - ky_s * g.KW;
+        }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             int c = tid + 256 * i;
             int k = kt * BK + (c % CPR) * EPC;
             bool ok = a_ok[i] && k < K;
-            int tap = 0, ch = k;
-            if (!is1x1) { tap = k / C; ch = k - tap * C; }
-            int ky = tap / g.KW, kx = tap - ky * g.KW;
+            int tap = 0, ch = k, ky, kx;
+            if (tap_uniform) {
+                ch = ch_s + (c % CPR) * EPC; ky = ky_s; kx = kx_s;
+            } else {
+                if (!is1x1) { tap = k / C; ch = k - tap * C; }
+                ky = tap / g.KW; kx = tap - ky * g.KW;
+            }
             int iy = a_y[i] + ky, ix = a_x[i] + kx;
             // ups = 1: the conv runs on the nearest-neighbour 2x upsampled image (never materialised)
             ok = ok && iy >= 0 && iy < (g.H << g.ups) && ix >= 0 && ix < (g.W << g.ups);

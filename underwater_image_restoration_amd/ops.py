@@ -343,3 +343,11 @@ def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cou
     Ho, Wo = out_nchw.shape[2], out_nchw.shape[3]
     _lib.check(lib.uwir_tail_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream()),
                "tail_conv3x3")
+
+
+def affine_cast(x: torch.Tensor, B: int, n: int, C_: int, a, s, out: torch.Tensor) -> None:
+    """out[m, c] = a[b, c] * x[m, c] + s[b, c] (b = m // n); x fp32, out fp32 / bf16."""
+    _f32(x, a, s)
+    lib = _lib.load()
+    _lib.check(lib.uwir_affine_cast(_p(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream()),
+               "affine_cast")

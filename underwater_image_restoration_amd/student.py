@@ -260,7 +260,14 @@ class NAFNetWFIGate(nn.Module):
         rs, rh = small("rs", Cw), small("rh", Cw)
         ops.chan_attn_fold(a1, s1, cw, rs, rh)
         qkv_base = buf("qkvb", 3 * Cw, adt)
-        ops.conv_gemm(hf, bp["qkv_w"], qkv_base, B=B, H=h, W=w, C_=Cw, N=3 * Cw, a_scale=a1, a_shift=s1, bias=bp["qkv_b"])
+        bf = adt == torch.bfloat16
+        if bf:  # bf16: one cast pass (norm applied) buys the LDS-DMA GEMM path; fp32: normalise-on-load
+            xn = buf("xn", Cw, adt)
+            ops.affine_cast(hf, B, n, Cw, a1, s1, xn)
+            ops.conv_gemm(xn, bp["qkv_w"], qkv_base, B=B, H=h, W=w, C_=Cw, N=3 * Cw, bias=bp["qkv_b"])
+        else:
+            ops.conv_gemm(hf, bp["qkv_w"], qkv_base, B=B, H=h, W=w, C_=Cw, N=3 * Cw, a_scale=a1, a_shift=s1,
+                          bias=bp["qkv_b"])
         ms = buf("ms", 9 * Cw, adt)
         ops.dwconv_ms(qkv_base, B, h, w, 3 * Cw, bp["dw_t"], bp["dw_b"], ms)
         qkv = buf("qkv", 3 * Cw, adt)
@@ -275,8 +282,12 @@ class NAFNetWFIGate(nn.Module):
         o, ln_ = bp["norm2_ss"]
         ops.ln2d_affine(x1, B, n, Cw, _EPS, bp["norm2_g"], bp["norm2_b"], cond_all[:, o:o + ln_], a2, s2, None, None, ws)
         hidden = buf("ffh", 2 * Cw, adt)
-        ops.conv_gemm(x1, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, a_scale=a2, a_shift=s2, bias=bp["ffn0_b"],
-                      act=ops.ACT_GELU)
+        if bf:
+            ops.affine_cast(x1, B, n, Cw, a2, s2, xn)
+            ops.conv_gemm(xn, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, bias=bp["ffn0_b"], act=ops.ACT_GELU)
+        else:
+            ops.conv_gemm(x1, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, a_scale=a2, a_shift=s2,
+                          bias=bp["ffn0_b"], act=ops.ACT_GELU)
         hf_out = hf  # hf is dead after the proj GEMM: reuse its storage
         ops.conv_gemm(hidden, bp["ffn2_w"], hf_out, B=B, H=h, W=w, C_=2 * Cw, N=Cw, bias=bp["ffn2_b"], res=x1)
 
