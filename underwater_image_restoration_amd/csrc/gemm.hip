@@ -31,11 +31,20 @@ template <> struct RawChunk<float, 8> { float4 lo, hi; };
 template <> struct RawChunk<float, 4> { float4 lo; };
 template <> struct RawChunk<bf16_t, 8> { bf16x8 v; };
 
+// Output-channel permutation inside each 64-wide wave column block.  LDS row rho = j*16 + r of the weight tile holds
+// channel pi(rho) = (r>>2)*16 + j*4 + (r&3) (an involution: it swaps the two 2-bit fields), so that after the
+// transposed MFMA the lane with fq = lane>>4 owns the 16 CONSECUTIVE channels fq*16 .. fq*16+15 of its pixel
+// (acc[i][j][e] <-> channel fq*16 + j*4 + e): bias / residual loads and the stores are 32-64 contiguous bytes per lane.
+__device__ __forceinline__ int chan_perm(int rho) {
+    return (rho & 64) | (((rho >> 2) & 3) << 4) | (((rho >> 4) & 3) << 2) | (rho & 3);
+}
+
 // ---- shared epilogue: the lane holds, per (i, j) MFMA tile, pixel m = m_base + i*16 + fr and the 4
-//      consecutive channels n = n_base + j*16 + fq*4 .. +3
+//      consecutive channels n = n_base + fq*16 + j*4 .. +3
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], int M, int m_base,
                                               int n_base, int fr, int fq) {
+    static_assert(TN == 4, "the channel permutation assumes 4 MFMA tiles per 64-channel wave block");
     const int N = g.N;
     const int OHW = g.OH * g.OW;
     const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
@@ -47,11 +56,13 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
         int b = m / OHW;
         size_t out_row = (size_t)m;
         int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
+        float vv[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            int n = n_base + j * 16 + fq * 4;
+            int n = n_base + fq * 16 + j * 4;
+            float* v = vv[j];
+            v[0] = acc[i][j][0]; v[1] = acc[i][j][1]; v[2] = acc[i][j][2]; v[3] = acc[i][j][3];
             if (n >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
             if (g.batch_scale) {
                 float4 t = load4(g.batch_scale + (size_t)b * bld + n);
@@ -88,16 +99,37 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
                 o.w = v[3] * t.w + (1.f - v[3]) * f.w;
                 store4(g.blend_out + out_row * g.ld_blend_out + n, o);
             }
-            if (g.out) {
+        }
+        if (!g.out) continue;
+        // bf16 rows, plain layout: two 16-byte stores cover the lane's 16 channels (when 8-channel groups are whole
+        // and the row base is 16-byte aligned); everything else goes out as 4-channel pieces
+        const bool wide = g.out_dtype == UWIR_BF16 && g.store_mode == 0 && (N % 8 == 0) && (g.ldo % 8 == 0) &&
+                          (((uintptr_t)g.out & 15) == 0);
+#pragma unroll
+        for (int jp = 0; jp < TN; jp += 2) {
+            int n = n_base + fq * 16 + jp * 4;
+            if (wide) {
+                if (n < N) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)vv[jp][e]; o[4 + e] = (bf16_t)vv[jp + 1][e]; }
+                    *reinterpret_cast<bf16x8*>((bf16_t*)g.out + out_row * g.ldo + n) = o;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = jp; j < jp + 2; ++j) {
+                int nj = n_base + fq * 16 + j * 4;
+                if (nj >= N) continue;
                 size_t off;
                 if (g.store_mode == 1) {
-                    int qd = n / Cout4, co = n - qd * Cout4;
+                    int qd = nj / Cout4, co = nj - qd * Cout4;
                     int dy = qd >> 1, dx = qd & 1;
                     off = (((size_t)b * 2 * g.OH + 2 * oy + dy) * (2 * g.OW) + 2 * ox + dx) * g.ldo + co;
                 } else {
-                    off = out_row * g.ldo + n;
+                    off = out_row * g.ldo + nj;
                 }
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                float4 o = make_float4(vv[j][0], vv[j][1], vv[j][2], vv[j][3]);
                 if (g.out_dtype == UWIR_F32) store4((float*)g.out + off, o);
                 else store4((bf16_t*)g.out + off, o);
             }
@@ -252,7 +284,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             int c = tid + 256 * i;
-            TC* dst = &sB[buf][(c / CPR) * BKP + (c % CPR) * EPC];
+            TC* dst = &sB[buf][chan_perm(c / CPR) * BKP + (c % CPR) * EPC];  // channel nn lives in LDS row pi(nn)
             if constexpr (sizeof(TC) == 4) *reinterpret_cast<float4*>(dst) = rb[i].lo;
             else *reinterpret_cast<bf16x8*>(dst) = rb[i].v;
         }
@@ -347,7 +379,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     for (int i = 0; i < 4; ++i) {
         int r = wave * 32 + i * 8 + prow;
         int gch = pch ^ (r & 7);
-        int am = min(m0 + r, M - 1), bn = min(n0 + r, N - 1);  // clamp: rows past the edge are never stored
+        int am = min(m0 + r, M - 1), bn = min(n0 + chan_perm(r), N - 1);  // LDS row r holds channel pi(r); clamp: rows
+                                                                          // past the edge are never stored
         a_src[i] = A + (size_t)am * g.lda + gch * 8;
         b_src[i] = Wt + (size_t)bn * K + gch * 8;
     }
