@@ -352,10 +352,14 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 // again on the fragment read.  One barrier per K tile: tile t+1 is in flight while tile t feeds
 // 32 v_mfma_f32_16x16x32_bf16 per wave.
 // ------------------------------------------------------------------------------------------
+// NBUF = 2: tile t+1 streams in while tile t computes (64 KiB LDS, 2 blocks / CU).
+// NBUF = 1: load -> compute per tile (32 KiB LDS, 4 blocks / CU): twice the resident blocks hide more latency than
+// the intra-block overlap does (see launch_gemm) -- this is the variant in use.
+template <int NBUF>
 __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     constexpr int BM = 128, BN = 128, BK = 64, TM = 4, TN = 4;
     constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-    __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];  // [buf][A|B]
+    __shared__ __attribute__((aligned(1024))) char smem[2 * NBUF * TILE_BYTES];  // [buf][A|B]
 
     const uwir_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -413,11 +417,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     const int sw = fr & 7;
 
     const int nk = K / BK;
-    stage(0, 0);
-    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+    auto compute = [&](int buf) {
         const char* la = smem + buf * 2 * TILE_BYTES;
         const char* lb = la + TILE_BYTES;
 #pragma unroll
@@ -434,7 +434,23 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if constexpr (NBUF == 2) {
+        stage(0, 0);
+        __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            stage(0, kt);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
     gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
 }
@@ -454,7 +470,10 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
     if (glds_eligible(p.a, p.K)) {
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3(p.nblocks), dim3(256), 0, stream, p);
+        // measured on MI355X (tools/bench_gemm.py): the single-buffered form wins at every K of this path, e.g.
+        // M262144 N384: K192 0.155 -> 0.124 ms, K768 0.303 -> 0.256; M262144 N576 K1728 0.796 -> 0.689;
+        // M16384 N2304 K6912 0.641 -> 0.609.  Four resident blocks per CU hide more than intra-block overlap.
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<1>, dim3(p.nblocks), dim3(256), 0, stream, p);
         UWIR_LAUNCH_CHECK("conv_gemm(glds)");
         return UWIR_OK;
     }
