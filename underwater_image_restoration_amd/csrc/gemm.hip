@@ -138,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
 }
 
 
-template <typename TC, typename TA, int BN>
+template <typename TC, typename TA, int BN, int NB>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     using Cfg = MmaCfg<TC>;
     constexpr int BM = 128, BK = Cfg::BK, EPC = Cfg::EPC, BKP = BK + Cfg::PAD, CPR = BK / EPC;
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N, WM = BM / WAVES_M, TM = WM / 16, TN = 4;
     constexpr int KSTEPS = BK / Cfg::KSTEP;
 
-    __shared__ __attribute__((aligned(16))) TC sA[2][BM * BKP];
-    __shared__ __attribute__((aligned(16))) TC sB[2][BN * BKP];
+    __shared__ __attribute__((aligned(16))) TC sA[NB][BM * BKP];
+    __shared__ __attribute__((aligned(16))) TC sB[NB][BN * BKP];
 
     const uwir_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,14 +331,25 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     };
 
     const int nk = (K + BK - 1) / BK;
-    load_regs(0);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_regs(kt + 1);
-        compute(kt & 1);
-        if (kt + 1 < nk) store_lds((kt + 1) & 1);
+    if constexpr (NB == 2) {
+        load_regs(0);
+        store_lds(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_regs(kt + 1);
+            compute(kt & 1);
+            if (kt + 1 < nk) store_lds((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {  // one LDS buffer, register prefetch of the next tile across the compute
+        load_regs(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            store_lds(0);
+            __syncthreads();
+            if (kt + 1 < nk) load_regs(kt + 1);
+            compute(0);
+            __syncthreads();
+        }
     }
 
     gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
@@ -477,10 +488,12 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
         UWIR_LAUNCH_CHECK("conv_gemm(glds)");
         return UWIR_OK;
     }
+    // one LDS buffer + register prefetch (NB = 1): half the LDS, more resident blocks; measured 13.0 -> 11.5 ms on the
+    // IR-SDE UNet step (B=8, 256^2, bf16) against the double-buffered form, neutral on the student
     if (bn == 64)
-        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 64>), dim3(p.nblocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 64, 1>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 128>), dim3(p.nblocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 128, 1>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm");
     return UWIR_OK;
 }

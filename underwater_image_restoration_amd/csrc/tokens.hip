@@ -9,14 +9,19 @@
 // IR-SDE UNet, U/models/modules/module_util.py:77-86).  One wave per row; the row is read three
 // times but only the first read leaves the cache hierarchy.
 // ------------------------------------------------------------------------------------------
-template <typename TY>
+// G = lanes that share one row (64, 32, 16 or 8): narrow rows (C = 64 -> 16 float4) would leave most of a wave idle,
+// so a wave handles 64 / G rows and the reductions stay inside the G-lane group.
+template <typename TY, int G>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ x, size_t ldx, int M, int C4,
                                                       const float* __restrict__ add, int add_period, int add_ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, const float* res, size_t ldr, TY* y, size_t ldy) {
-    const int lane = threadIdx.x % UWIR_WAVE;
-    const int row = blockIdx.x * (blockDim.x / UWIR_WAVE) + threadIdx.x / UWIR_WAVE;
-    if (row >= M) return;  // whole wave
+    constexpr int RPW = UWIR_WAVE / G;  // rows per wave
+    const int lane = threadIdx.x % UWIR_WAVE, sub = lane % G;
+    const int wave = blockIdx.x * (blockDim.x / UWIR_WAVE) + threadIdx.x / UWIR_WAVE;
+    const int row_raw = wave * RPW + lane / G;
+    const bool live = row_raw < M;
+    const int row = live ? row_raw : M - 1;  // dead groups shadow the last row (no stores) so shuffles stay convergent
     const float* xr = x + (size_t)row * ldx;
     const float* ar = add ? add + (size_t)(row % add_period) * add_ld : nullptr;
     const float invC = 1.f / (float)(4 * C4);
@@ -29,25 +34,26 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
         return v;
     };
     float s = 0.f;
-    for (int c4 = lane; c4 < C4; c4 += UWIR_WAVE) {
+    for (int c4 = sub; c4 < C4; c4 += G) {
         float4 v = ld(c4);
         s += (v.x + v.y) + (v.z + v.w);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float mean = s * invC;
     float q = 0.f;
-    for (int c4 = lane; c4 < C4; c4 += UWIR_WAVE) {
+    for (int c4 = sub; c4 < C4; c4 += G) {
         float4 v = ld(c4);
         float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    for (int off = G / 2; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    if (!live) return;
     const float rstd = 1.f / sqrtf(q * invC + eps);
     TY* yr = y + (size_t)row * ldy;
     const float* rr = res ? res + (size_t)row * ldr : nullptr;
-    for (int c4 = lane; c4 < C4; c4 += UWIR_WAVE) {
+    for (int c4 = sub; c4 < C4; c4 += G) {
         float4 v = ld(c4), g = load4(gamma + 4 * c4);
         float4 b = beta ? load4(beta + 4 * c4) : make_float4(0, 0, 0, 0);
         float4 o;
@@ -63,6 +69,21 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
     }
 }
 
+template <typename TY>
+static void launch_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
+                           const float* gamma, const float* beta, float eps, const float* res, size_t ldr, TY* y,
+                           size_t ldy, hipStream_t s) {
+    const int C4 = C / 4;
+#define LN_LAUNCH(G)                                                                                                   \
+    hipLaunchKernelGGL((ln_rows_kernel<TY, G>), dim3(ceil_div(M, 4 * (UWIR_WAVE / G))), dim3(256), 0, s, x, ldx, M, C4, \
+                       add, add_period, add_ld, gamma, beta, eps, res, ldr, y, ldy)
+    if (C4 <= 8) LN_LAUNCH(8);
+    else if (C4 <= 16) LN_LAUNCH(16);
+    else if (C4 <= 32) LN_LAUNCH(32);
+    else LN_LAUNCH(64);
+#undef LN_LAUNCH
+}
+
 extern "C" int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
                             const float* gamma, const float* beta, float eps, const float* res, size_t ldr, void* y,
                             int y_dtype, size_t ldy, uwir_stream_t stream) {
@@ -73,13 +94,12 @@ extern "C" int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const floa
     UWIR_CHECK(!res || (ldr >= (size_t)C && ldr % 4 == 0), "ln_rows: bad residual stride");
     UWIR_CHECK(y_dtype == UWIR_F32 || y_dtype == UWIR_BF16, "ln_rows: bad output dtype");
     UWIR_CHECK((const void*)x != (const void*)y || y_dtype == UWIR_F32, "ln_rows: in-place needs an fp32 output");
-    dim3 grid(ceil_div(M, 4));
     if (y_dtype == UWIR_F32)
-        hipLaunchKernelGGL(ln_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, C / 4, add,
-                           add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy);
+        launch_ln_rows<float>(x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy,
+                              (hipStream_t)stream);
     else
-        hipLaunchKernelGGL(ln_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, C / 4, add,
-                           add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy);
+        launch_ln_rows<bf16_t>(x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy,
+                               (hipStream_t)stream);
     UWIR_LAUNCH_CHECK("ln_rows");
     return UWIR_OK;
 }
