@@ -476,6 +476,8 @@ template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
     int bn = p.a.N <= 64 ? 64 : 128;
+    // few-block launches (deep, narrow levels: M = 8192 rows): halve the N tile to double the blocks on the 256 CUs
+    if (bn == 128 && (long long)ceil_div(p.M, 128) * ceil_div(p.a.N, 128) < 512 && !glds_eligible(p.a, p.K)) bn = 64;
     p.tiles_n = ceil_div(p.a.N, bn);
     long long nb = (long long)ceil_div(p.M, 128) * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
