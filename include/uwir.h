@@ -247,6 +247,15 @@ int uwir_softmax_rows(const float* x, int ldx, int B, int C, const float* mul, f
 int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                       float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
 
+/* ---- evaluation metrics of the student's eval loops, underwater_ir/student/train_student.py:70-95 ----------------
+ * x, y NCHW fp32 [B,C,H,W] -> out [B,3] = per image (ssim_loss, mse, psnr): ssim_loss = mean(1 - ssim_map) with the
+ * 11x11 uniform window (avg_pool2d, zero padding counted, variances clamped at 0, eps 1e-8; ssim_value = 1 - that),
+ * psnr = 10 log10(1/mse) capped at 100 dB for mse <= 1e-10.  c1 = 0.01^2, c2 = 0.03^2 in the reference.
+ * workspace >= uwir_image_metrics_workspace_bytes(B,C,H,W), 8-byte aligned. */
+size_t uwir_image_metrics_workspace_bytes(int B, int C, int H, int W);
+int uwir_image_metrics(const float* x_nchw, const float* y_nchw, int B, int C, int H, int W, float c1, float c2, float* out,
+                       void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

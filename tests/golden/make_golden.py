@@ -237,10 +237,34 @@ def unet_case(name: str, cfg: dict) -> None:
     print("unet", name, "out |max|", float(np.abs(store["out0"]).max()), "fp32-vs-fp64", float(np.abs(store["out0"] - store["out0_f64"]).max()))
 
 
+def metrics_case() -> None:
+    """ssim_loss / psnr_value from the reference's standalone copy (test_ssim.py:10-38; identical to
+    train_student.py:70-95, whose package import needs torchvision)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_test_ssim", "/root/reference/test_ssim.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(41)
+    store = {}
+    base = torch.rand(2, 3, 40, 56, generator=g)
+    cases = {"noisy": (base, (base + 0.05 * torch.randn(base.shape, generator=g)).clamp(0, 1)),
+             "random": (base, torch.rand(base.shape, generator=g)),
+             "identical": (base, base.clone()),
+             "flat": (torch.full((1, 3, 24, 24), 0.5), torch.full((1, 3, 24, 24), 0.5) + 1e-3),
+             "small": (torch.rand(1, 1, 7, 5, generator=g), torch.rand(1, 1, 7, 5, generator=g))}
+    for name, (a, b) in cases.items():
+        store[f"{name}_x"], store[f"{name}_y"] = a.numpy(), b.numpy()
+        store[f"{name}_ssim_loss"] = np.float64(float(mod.ssim_loss(a.double(), b.double())))
+        store[f"{name}_ssim_loss_f32"] = np.float32(float(mod.ssim_loss(a, b)))
+        store[f"{name}_psnr"] = np.float64(mod.psnr_value(a.double(), b.double()))
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **store)
+    print("metrics:", {k: float(v) for k, v in store.items() if k.endswith("ssim_loss")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet"}
+    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics"}
     if "dwt" in which:
         dwt_case()
     if "student" in which:
@@ -254,3 +278,5 @@ if __name__ == "__main__":
     if "unet" in which:
         for name, cfg in UNET_CASES.items():
             unet_case(name, cfg)
+    if "metrics" in which:
+        metrics_case()

@@ -351,3 +351,17 @@ def affine_cast(x: torch.Tensor, B: int, n: int, C_: int, a, s, out: torch.Tenso
     lib = _lib.load()
     _lib.check(lib.uwir_affine_cast(_p(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream()),
                "affine_cast")
+
+
+def image_metrics(x: torch.Tensor, y: torch.Tensor, c1: float = 0.01 ** 2, c2: float = 0.03 ** 2) -> torch.Tensor:
+    """-> [B, 3] = per image (ssim_loss, mse, psnr) of NCHW fp32 batches; see uwir_image_metrics."""
+    _f32(x, y)
+    lib = _lib.load()
+    if x.shape != y.shape or x.dim() != 4 or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("image_metrics: x and y must be contiguous NCHW tensors of one shape")
+    B, C_, H, W = x.shape
+    ws = torch.empty(int(lib.uwir_image_metrics_workspace_bytes(B, C_, H, W)) // 8, dtype=torch.float64, device=x.device)
+    out = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+    _lib.check(lib.uwir_image_metrics(_p(x), _p(y), B, C_, H, W, c1, c2, _p(out), _p(ws), ws.numel() * 8, _stream()),
+               "image_metrics")
+    return out
