@@ -33,3 +33,27 @@ def test_metrics_match_reference_and_oracle():
     assert metrics.ssim_value(x.cuda(), x.cuda()) > 0.999999 and metrics.psnr_value(x.cuda(), x.cuda()) == 100.0
     with pytest.raises(RuntimeError):
         metrics.ssim_loss(x, y)
+
+
+def test_eval_batch_from_files(tmp_path):
+    """f4 + f2 together: pseudo-label files -> model dims -> checkpoint (strict=False) -> forward -> PSNR/SSIM sums."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from underwater_image_restoration_amd import formats
+    from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict
+    gen = torch.Generator().manual_seed(4)
+    pl = [{"z_d": torch.randn(20, generator=gen), "masks": torch.rand(10, 7, 7, generator=gen),
+           "global_prob": torch.rand(10, generator=gen)} for _ in range(2)]
+    for i, p in enumerate(pl):
+        torch.save(p, tmp_path / f"im{i}.pt")
+    loaded = [formats.load_pseudo_label(tmp_path, f"im{i}.png") for i in range(2)]
+    sd = synth_state_dict(student_param_shapes(cond_dim=20, num_masks=10, num_degradation_types=10), seed=1)
+    sd["extra.unused"] = torch.zeros(1)                 # strict=False tolerates foreign keys (infer_adapt.py:159)
+    torch.save(sd, tmp_path / "student.pth")
+    model, z1, m1 = formats.build_student_from_files(loaded[0], tmp_path / "student.pth")
+    assert z1.shape == (1, 20) and m1.shape == (1, 10, 7, 7)
+    lq, gt = torch.rand(2, 3, 32, 32, generator=gen).cuda(), torch.rand(2, 3, 32, 32, generator=gen).cuda()
+    out, psnr_sum, ssim_sum, count = formats.eval_batch(model, lq, gt, loaded)
+    ref_p = sum(M.psnr_value(out[i:i + 1].double().cpu().clamp(0, 1), gt[i:i + 1].double().cpu()) for i in range(2))
+    ref_s = sum(M.ssim_value(out[i:i + 1].double().cpu().clamp(0, 1), gt[i:i + 1].double().cpu()) for i in range(2))
+    assert count == 2 and abs(psnr_sum - ref_p) < 1e-3 and abs(ssim_sum - ref_s) < 1e-5
