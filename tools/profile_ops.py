@@ -60,7 +60,9 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-fast-attn", action="store_true")
     args = ap.parse_args()
+    ops._NO_FAST = args.no_fast_attn
     wrap("conv_gemm", gemm_tag)
     wrap("flash_attn", attn_tag)
     for nm in ("dwt2", "idwt2", "ln2d_affine", "dwconv_ms", "fft2_amp_phase", "ifft2_polar_add", "stem_conv3x3", "head_conv3x3",

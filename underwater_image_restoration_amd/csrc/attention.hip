@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
                 auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                 q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 const float ub = sqrtf(q2 * km2) * 1.002f + 1e-3f;
-                ok = ok && ub <= 60.f;
+                ok = ok && ub <= 90.f;
             }
             if constexpr (MODE == 1) {
                 if (__syncthreads_or(!ok)) {  // block-uniform: leave the whole block to the online-max launch

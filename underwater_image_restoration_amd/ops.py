@@ -154,6 +154,7 @@ def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, ou
 
 
 _ATTN_WS = {}
+_NO_FAST = False  # debugging aid (tools/): force the online-max attention loop
 
 
 def _attn_workspace(dev, B: int, n: int, heads: int) -> torch.Tensor:
@@ -177,7 +178,7 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    ws = _attn_workspace(q.device, B, n, heads) if (fast and dt == BF16) else None
+    ws = _attn_workspace(q.device, B, n, heads) if (fast and dt == BF16 and not _NO_FAST) else None
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
                                    0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
                                    0 if o2 is None else _ld(o2), _dt(o1), _p(ws), 0 if ws is None else ws.numel() * 4,
