@@ -141,8 +141,13 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * workspace (optional, >= uwir_flash_attn_workspace_bytes(B, n, heads), 4-byte aligned): enables the bf16 fast path --
  * a pre-pass stores max_k |k|^2 per (b, head) there; where the a-priori score bound |c q| * max|k| is <= 60 (log2
  * units) exp2 cannot leave the fp32/bf16 range, the (mathematically cancelling) softmax shift is dropped and no
- * running max / rescale is computed; blocks with a larger bound run the online-max loop. */
+ * running max / rescale is computed; blocks with a larger bound run the online-max loop.
+ * With >= uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) bytes, 256-byte aligned, long bf16 sequences with
+ * hd 16 or 32 (n >= 2048, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
+ * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier.  The
+ * results are the same function of the inputs to bf16 rounding; shapes outside that range return the small size. */
 size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads);
+size_t uwir_flash_attn_packed_workspace_bytes(int B, int n, int heads, int hd, int nv);
 int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1, const void* v2,
                     int ldv2, int dtype, int B, int n, int heads, int hd, float scale, void* o1, int ldo1,
                     void* o2, int ldo2, int out_dtype, void* workspace, size_t workspace_bytes, uwir_stream_t stream);

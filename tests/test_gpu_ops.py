@@ -527,6 +527,62 @@ def test_flash_attn_bf16_fast_path_and_fallback(ops, cfg):
                 assert torch.equal(a_, b_)
 
 
+def _attn_ref_cuda(q, k, vs, b, n, heads, hd):
+    """fp64 reference on the device, one (batch, head) at a time (long sequences: the n x n matrix stays small)."""
+    outs = [torch.empty(b * n, heads * hd, dtype=torch.float64, device="cuda") for _ in vs]
+    for bi in range(b):
+        rows = slice(bi * n, (bi + 1) * n)
+        for h in range(heads):
+            cols = slice(h * hd, (h + 1) * hd)
+            a = torch.softmax(q[rows, cols].double() @ k[rows, cols].double().T / math.sqrt(hd), dim=-1)
+            for o, v in zip(outs, vs):
+                o[rows, cols] = a @ v[rows, cols].double()
+    return outs
+
+
+@pytest.mark.parametrize("cfg", [(1, 4096, 16, 16, 1), (1, 2100, 32, 16, 2), (1, 2049, 32, 32, 1), (2, 2500, 13, 32, 2),
+                                 (1, 2048, 32, 16, 1)])
+def test_flash_attn_packed_stream(ops, cfg):
+    """Long bf16 sequences with hd 16 / 32 take the packed-stream kernels (pre-packed K / V^T fragments, no LDS):
+    parity with the fp64 softmax attention, agreement with the LDS-staged kernels, ragged n (keys padded to 32,
+    query blocks partly empty), strided q|k|v views, and the per-block fallback for unbounded scores."""
+    b, n, heads, hd, nv = cfg
+    lib_need = ops._lib.load().uwir_flash_attn_packed_workspace_bytes(b, n, heads, hd, nv)
+    assert lib_need > ops._lib.load().uwir_flash_attn_workspace_bytes(b, n, heads) + n * heads * hd  # the packed path is on
+    g = torch.Generator().manual_seed(23)
+    wdt = heads * hd
+    qkv = (torch.randn(b * n, 3 * wdt + 8, generator=g)).bfloat16().cuda()
+    q, k, v = qkv[:, :wdt], qkv[:, wdt:2 * wdt], qkv[:, 2 * wdt:3 * wdt]
+    v2 = torch.randn(b * n, wdt, generator=g).bfloat16().cuda() if nv == 2 else None
+    vs = [v] + ([v2] if nv == 2 else [])
+    refs = _attn_ref_cuda(q, k, vs, b, n, heads, hd)
+    outs = {}
+    for packed in (True, False):
+        ops._PACKED = packed
+        try:
+            o = [torch.full((b * n, wdt + 4), -9.0, device="cuda") for _ in range(nv)]
+            ops.flash_attn(q, k, v, v2, b, n, heads, hd, 1.0 / math.sqrt(hd), o[0][:, :wdt], o[1][:, :wdt] if nv == 2 else None)
+        finally:
+            ops._PACKED = True
+        outs[packed] = o
+        for got, ref in zip(o, refs):
+            assert err(got[:, :wdt], ref) < 3e-2, packed
+            assert float(got[:, wdt:].max()) == -9.0
+    for a_, b_ in zip(outs[True], outs[False]):  # same bf16 operands, same exp2: only the summation order differs
+        assert float((a_ - b_).abs().max()) < 2e-3
+    # one batch element with huge scores: its blocks must fall back to the online-max loop (bit-equal to it), the
+    # others stay on the stream kernel
+    q2 = q.clone()
+    q2[:n] = (q2[:n].float() * 40).bfloat16()
+    o_p = torch.empty(b * n, wdt, device="cuda")
+    o_o = torch.empty(b * n, wdt, device="cuda")
+    ops.flash_attn(q2, k, v, None, b, n, heads, hd, 1.0 / math.sqrt(hd), o_p, None)
+    ops.flash_attn(q2, k, v, None, b, n, heads, hd, 1.0 / math.sqrt(hd), o_o, None, fast=False)
+    assert torch.equal(o_p[:n], o_o[:n]) and bool(torch.isfinite(o_p).all())
+    if b > 1:
+        assert err(o_p[n:], refs[0][n:]) < 3e-2
+
+
 def test_affine_cast(ops):
     g = torch.Generator().manual_seed(20)
     b, n, c = 3, 37, 24

@@ -9,7 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from underwater_image_restoration_amd import ops  # noqa: E402
 
 
-def run(B, n, heads, hd, nv, amp=0.5, fast=True, reps=10):
+def run(B, n, heads, hd, nv, amp=0.5, fast=True, reps=10, packed=True):
+    ops._PACKED = packed
     w = heads * hd
     q, k, v1, v2 = ((torch.randn(B * n, w, device="cuda") * amp).bfloat16() for _ in range(4))
     o1 = torch.empty(B * n, w, device="cuda", dtype=torch.bfloat16)
@@ -27,7 +28,7 @@ def run(B, n, heads, hd, nv, amp=0.5, fast=True, reps=10):
     ms = e0.elapsed_time(e1) / reps
     fl = (2 + 2 * nv) * B * heads * float(n) * n * hd
     units = B * heads * (n / 32) ** 2 / 1024
-    print(f"B{B} n{n} h{heads} hd{hd} nv{nv} amp{amp} fast={fast}: {ms:.3f} ms {fl / ms / 1e9:6.0f} TF/s "
+    print(f"B{B} n{n} h{heads} hd{hd} nv{nv} amp{amp} fast={fast} packed={packed}: {ms:.3f} ms {fl / ms / 1e9:6.0f} TF/s "
           f"{ms * 1e-3 * 2.4e9 / units:5.0f} cyc/unit")
 
 
@@ -41,4 +42,5 @@ if __name__ == "__main__":
         for cfg in ((16, 16384, 12, 16, 1), (16, 16384, 4, 16, 2), (16, 4096, 12, 32, 1), (16, 4096, 4, 32, 2),
                     (16, 1024, 12, 64, 1), (16, 1024, 4, 64, 2), (16, 50, 12, 64, 1), (4, 65536, 12, 16, 1)):
             run(*cfg, fast=True)
+            run(*cfg, fast=True, packed=False)
             run(*cfg, fast=False)

@@ -483,6 +483,333 @@ __global__ void __launch_bounds__(256) attn_kmax_kernel(const bf16_t* __restrict
     if ((threadIdx.x & 63) == 0) atomicMax(out + b * heads + head, __float_as_uint(m));
 }
 
+// ------------------------------------------------------------------------------------------
+// Packed-stream fast path (bf16, hd 16 / 32, long sequences).  The staging work of the LDS kernel above -- strided
+// K / V gathers, the V transposition through 2-byte LDS stores, a barrier per 64 keys -- is per (block, tile); at
+// hd = 16 the loop is bound by exp issue and every other instruction in it costs throughput.  Here a pre-pass
+// (attn_pack_kernel, one read of K and V per call, it also yields max|k|^2 for the score bound) lays both operands out
+// exactly as the MFMA fragments want them:
+//   Kp  [b*heads+head][npad keys][HD]                      one 32-key block = one contiguous run
+//   Vtp [b*heads+head][npad/16 key groups][ROWS][16 keys]  V^T rows (d of V1, then V2, then a ones row when a row of
+//                                                          the 32-row MFMA tile is spare), keys in accumulator order
+// and the main kernel has no LDS and no barrier: every wave streams 16-byte fragments straight into registers with
+// buffer loads (per-lane offset fixed, the block offset is a scalar), two key blocks ahead of their use, for 32*QG
+// queries.  Keys in [n, npad) are packed as K = 0, V = 0, ones = 0: they add exp2(0) * 0 to every sum (without a
+// ones row the denominator's MFMA counts them as 1 each; npad - n is subtracted at the end).
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define PK_KEYS 256  // keys per block of the pack pre-pass
+
+template <int HD, int NV> struct PackCfg {
+    static constexpr int DV = HD * NV, DG = (DV + 31) / 32;
+    static constexpr bool SUMROW = (DV % 32) != 0;
+    static constexpr int ROWS = DV + (SUMROW ? 1 : 0);
+};
+
+__host__ __device__ static inline size_t pk_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+template <int HD, int NV>
+__global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ v1,
+                                                        int ldv1, const bf16_t* __restrict__ v2, int ldv2, int n, int npad,
+                                                        int heads, bf16_t* __restrict__ Kp, bf16_t* __restrict__ Vtp,
+                                                        unsigned* __restrict__ kmax2) {
+    using P = PackCfg<HD, NV>;
+    constexpr int DV = P::DV, ROWS = P::ROWS, SV = DV + 2;  // LDS row stride (elements): odd dword count
+    __shared__ bf16_t sV[PK_KEYS * SV];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int bh = b * heads + head;
+    const int k0 = blockIdx.x * PK_KEYS, key = k0 + tid;
+    float m = 0.f;
+    if (key < npad) {
+        bf16_t* kd = Kp + ((size_t)bh * npad + key) * HD;
+        if (key < n) {
+            const size_t r = (size_t)b * n + key;
+            const bf16_t* kr = k + r * ldk + (size_t)head * HD;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                bf16x4 t = *reinterpret_cast<const bf16x4*>(kr + d);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float f = (float)t[e]; s = fmaf(f, f, s); }
+                *reinterpret_cast<bf16x4*>(kd + d) = t;
+            }
+            m = s;
+#pragma unroll
+            for (int vv = 0; vv < NV; ++vv) {
+                const bf16_t* vr = (vv == 0 ? v1 + r * ldv1 : v2 + r * ldv2) + (size_t)head * HD;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    bf16x4 t = *reinterpret_cast<const bf16x4*>(vr + d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sV[tid * SV + vv * HD + d + e] = t[e];
+                }
+            }
+        } else {
+            bf16x4 z;
+            z[0] = z[1] = z[2] = z[3] = (bf16_t)0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) *reinterpret_cast<bf16x4*>(kd + d) = z;
+#pragma unroll
+            for (int d = 0; d < DV; ++d) sV[tid * SV + d] = (bf16_t)0.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0 && m > 0.f) atomicMax(kmax2 + bh, __float_as_uint(m));
+    __syncthreads();
+    // one item = one V^T row of one 16-key group: 16 keys gathered in accumulator order, one 32-byte store
+    for (int item = tid; item < (PK_KEYS / 16) * ROWS; item += 256) {
+        const int kg = item / ROWS, row = item - kg * ROWS;
+        const int kbase = k0 + kg * 16;
+        if (kbase >= npad) continue;
+        bf16x8 o[2];
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            const int kk = 8 * ((pos >> 2) & 1) + 4 * (pos >> 3) + (pos & 3);  // bits 2 and 3 swapped (an involution)
+            bf16_t val;
+            if (row < DV) val = sV[(kg * 16 + kk) * SV + row];
+            else val = (bf16_t)((kbase + kk) < n ? 1.f : 0.f);
+            o[pos >> 3][pos & 7] = val;
+        }
+        bf16_t* dst = Vtp + (((size_t)bh * (npad / 16) + kbase / 16) * ROWS + row) * 16;
+        *reinterpret_cast<bf16x8*>(dst) = o[0];
+        *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
+    }
+}
+
+template <int HD, int NV, int QG, int PF>
+__global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t* __restrict__ Kp,
+                                                          const bf16_t* __restrict__ Vtp, int npad, int nqb, int nblocks) {
+    using P = PackCfg<HD, NV>;
+    constexpr int DV = P::DV, DG = P::DG, ROWS = P::ROWS, KS = HD / 16;
+    constexpr bool SUMROW = P::SUMROW;
+    constexpr int NSLOT = PF + 1;
+    // XCD-aware bijective remap: the blocks that share an XCD (bid % 8) walk a contiguous range of (b, head, query
+    // block), so the K / V^T stream of one (b, head) is served by one L2
+    int vid = blockIdx.x;
+    {
+        int q = nblocks / 8, r = nblocks % 8, xcd = vid % 8;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + vid / 8;
+    }
+    const int bh = vid / nqb, qb = vid - bh * nqb;
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int n = p.n;
+    const size_t row0 = (size_t)b * n;
+    const int qbase = qb * (128 * QG) + wave * (32 * QG) + lq;
+    const float c = p.c;
+
+    // ---- Q fragments (pre-multiplied by c: scores come out of the MFMA in the log2 domain) and the score bound
+    bf16x8 qf[QG][KS];
+    bool ok = true;
+    const float km2 = p.kmax2[bh];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int q_idx = qbase + 32 * g;
+        const bool qok = q_idx < n;
+        const bf16_t* qrow = (const bf16_t*)p.q + (size_t)head * HD + (row0 + (qok ? q_idx : 0)) * p.ldq;
+        float q2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x4 v = *reinterpret_cast<const bf16x4*>(qrow + 16 * ks + 8 * lh + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf16_t t = qok ? (c == 1.f ? v[e] : (bf16_t)((float)v[e] * c)) : (bf16_t)0.f;
+                    f[4 * half + e] = t;
+                    q2 = fmaf((float)t, (float)t, q2);
+                }
+            }
+            qf[g][ks] = f;
+        }
+        unsigned u = __float_as_uint(q2);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        ok = ok && (sqrtf(q2 * km2) * 1.002f + 1e-3f <= 90.f);
+    }
+    if (__syncthreads_or(!ok)) {  // block-uniform: leave the whole block to the online-max launch
+        if (tid == 0) p.flags[vid] = 1;
+        return;
+    }
+
+    // ---- fragment streams
+    const size_t kbytes = (size_t)npad * HD * 2, vbytes = (size_t)(npad / 16) * ROWS * 32;
+    __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Kp + (size_t)bh * kbytes), 0,
+                                                                   (int)kbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Vtp + (size_t)bh * vbytes), 0,
+                                                                   (int)vbytes, 0x00020000);
+    const int kvo = lq * (HD * 2) + lh * 16;
+    int vvo[DG];
+#pragma unroll
+    for (int dg = 0; dg < DG; ++dg) vvo[dg] = min(lq + 32 * dg, ROWS - 1) * 32 + lh * 16;
+
+    u32x4 kf[NSLOT][KS], vf[NSLOT][2][DG];
+    auto issue = [&](const int blk, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
+        const int ko = blk * (32 * HD * 2), vo = blk * (2 * ROWS * 32);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[S][ks] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo + ks * 32, ko, 0);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int dg = 0; dg < DG; ++dg)
+                vf[S][ss][dg] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo[dg], vo + ss * (ROWS * 32), 0);
+    };
+
+    f32x16 O[QG][DG], Lacc[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+        for (int dg = 0; dg < DG; ++dg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[g][dg][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Lacc[g][r] = 0.f;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
+
+    auto compute = [&](auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
+        f32x16 s[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[g][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kk = __builtin_bit_cast(bf16x8, kf[S][ks]);
+#pragma unroll
+            for (int g = 0; g < QG; ++g) s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kk, qf[g][ks], s[g], 0, 0, 0);
+        }
+        bf16x8 pb[QG][2];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[g][ss][j] = (bf16_t)__builtin_amdgcn_exp2f(s[g][8 * ss + j]);
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+            for (int dg = 0; dg < DG; ++dg) {
+                const bf16x8 vv = __builtin_bit_cast(bf16x8, vf[S][ss][dg]);
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    O[g][dg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pb[g][ss], O[g][dg], 0, 0, 0);
+            }
+            if constexpr (!SUMROW) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    Lacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[g][ss], Lacc[g], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nblk = npad / 32;
+    int i = 0;
+    if constexpr (PF == 2) {
+        issue(0, GIdx<0>{});
+        issue(1, GIdx<1>{});
+        for (; i + 3 <= nblk; i += 3) {  // loads past the last block return zeros (buffer bounds) and are never used
+            issue(i + 2, GIdx<2>{});
+            compute(GIdx<0>{});
+            issue(i + 3, GIdx<0>{});
+            compute(GIdx<1>{});
+            issue(i + 4, GIdx<1>{});
+            compute(GIdx<2>{});
+        }
+        if (i < nblk) compute(GIdx<0>{});
+        if (i + 1 < nblk) compute(GIdx<1>{});
+    } else {
+        issue(0, GIdx<0>{});
+        for (; i + 2 <= nblk; i += 2) {
+            issue(i + 1, GIdx<1>{});
+            compute(GIdx<0>{});
+            issue(i + 2, GIdx<0>{});
+            compute(GIdx<1>{});
+        }
+        if (i < nblk) compute(GIdx<0>{});
+    }
+
+    // ---- denominators, normalise, store (same accumulator layout as flash_attn_kernel)
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        float l;
+        if constexpr (SUMROW) {
+            constexpr int lr = DV % 32, rl = (lr & 3) + 4 * (lr >> 3), hl = (lr >> 2) & 1;
+            unsigned u = __float_as_uint(O[g][DG - 1][rl]);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            l = __uint_as_float(sw[hl]);
+        } else {
+            l = Lacc[g][0] - (float)(npad - n);
+        }
+        const int q_idx = qbase + 32 * g;
+        if (q_idx >= n) continue;
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int dg = 0; dg < DG; ++dg) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dg * 32 + 8 * rq + 4 * lh;
+                const int v = d / HD, dd = d % HD;
+                if (v < NV) {
+                    float4 o = make_float4(O[g][dg][4 * rq] * inv, O[g][dg][4 * rq + 1] * inv, O[g][dg][4 * rq + 2] * inv,
+                                           O[g][dg][4 * rq + 3] * inv);
+                    size_t off = (row0 + q_idx) * p.ldo[v] + (size_t)head * HD + dd;
+                    if (p.out_dtype == UWIR_F32) store4((float*)p.o[v] + off, o);
+                    else store4((bf16_t*)p.o[v] + off, o);
+                }
+            }
+        }
+    }
+}
+
+// workspace: [B*heads] max|k|^2, one int per 256-query block, then (packed path) Kp and Vtp, 256-byte aligned
+static size_t attn_hdr_bytes(int B, int n, int heads) {
+    return ((size_t)B * heads + (size_t)ceil_div(n, 128) * heads * B) * sizeof(float);
+}
+static bool attn_packed_shape(int B, int n, int heads, int hd, int nv) {
+    return (hd == 16 || hd == 32) && (nv == 1 || nv == 2) && n >= 2048 &&
+           (long long)ceil_div(n, 256) * heads * B >= 256;
+}
+static size_t attn_packed_bytes(int B, int n, int heads, int hd, int nv) {
+    const int npad = ceil_div(n, 32) * 32, dv = hd * nv, rows = dv + ((dv % 32) ? 1 : 0);
+    const size_t bh = (size_t)B * heads;
+    return pk_align256(attn_hdr_bytes(B, n, heads)) + pk_align256(bh * npad * hd * 2) + pk_align256(bh * (npad / 16) * rows * 32);
+}
+
+template <int HD, int NV, int QG, int PF>
+static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_t stream) {
+    using P = PackCfg<HD, NV>;
+    const int n = p.n, npad = ceil_div(n, 32) * 32;
+    const size_t bh = (size_t)B * p.heads;
+    char* base = (char*)workspace + pk_align256(attn_hdr_bytes(B, n, p.heads));
+    bf16_t* Kp = (bf16_t*)base;
+    bf16_t* Vtp = (bf16_t*)(base + pk_align256(bh * npad * HD * 2));
+    if ((size_t)npad * HD * 2 >= 0x7fffffffULL || (size_t)(npad / 16) * P::ROWS * 32 >= 0x7fffffffULL)
+        return uwir_set_error(UWIR_EINVAL, "flash_attn: sequence too long for the packed stream");
+    hipLaunchKernelGGL((attn_pack_kernel<HD, NV>), dim3(ceil_div(npad, PK_KEYS), p.heads, B), dim3(256), 0, stream,
+                       (const bf16_t*)p.k, p.ldk, (const bf16_t*)p.v[0], p.ldv[0], (const bf16_t*)p.v[1], p.ldv[1], n, npad,
+                       p.heads, Kp, Vtp, (unsigned*)workspace);
+    UWIR_LAUNCH_CHECK("flash_attn(pack)");
+    const int nqb = ceil_div(n, 128 * QG);
+    const long long nb = (long long)nqb * p.heads * B;
+    if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "flash_attn: grid too large");
+    hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF>), dim3((unsigned)nb), dim3(256), 0, stream, p, Kp, Vtp, npad, nqb,
+                       (int)nb);
+    // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
+    hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, QG, 2>), dim3(nqb, p.heads, B), dim3(256), 0, stream, p);
+    UWIR_LAUNCH_CHECK("flash_attn(stream)");
+    return UWIR_OK;
+}
+
 template <typename T, int HD>
 static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
     // big bf16 problems with hd <= 16: two query groups per wave (256 queries per block) and the split launch
@@ -510,11 +837,11 @@ static int launch_attn(const AttnP& p, int nv, int B, hipStream_t stream) {
     return launch_attn_nv<T, 64>(p, nv, B, stream);
 }
 
-// [B*heads] floats (max |k|^2) followed by one int per 256-query block (split-launch marks)
-static size_t attn_ws_bytes(int B, int n, int heads) {
-    return ((size_t)B * heads + (size_t)ceil_div(n, 256) * heads * B) * sizeof(float);
+extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads) { return attn_hdr_bytes(B, n, heads); }
+extern "C" size_t uwir_flash_attn_packed_workspace_bytes(int B, int n, int heads, int hd, int nv) {
+    if (B <= 0 || n <= 0 || heads <= 0 || !attn_packed_shape(B, n, heads, hd, nv)) return attn_hdr_bytes(B, n, heads);
+    return attn_packed_bytes(B, n, heads, hd, nv);
 }
-extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads) { return attn_ws_bytes(B, n, heads); }
 
 extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1,
                                const void* v2, int ldv2, int dtype, int B, int n, int heads, int hd, float scale,
@@ -546,16 +873,24 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     p.kmax2 = nullptr;
     p.flags = nullptr;
     if (dtype == UWIR_BF16 && workspace) {
-        UWIR_CHECK(workspace_bytes >= attn_ws_bytes(B, n, heads) && ((uintptr_t)workspace & 3) == 0,
-                   "flash_attn: workspace too small / misaligned");
+        const size_t hdr = attn_hdr_bytes(B, n, heads);
+        UWIR_CHECK(workspace_bytes >= hdr && ((uintptr_t)workspace & 3) == 0, "flash_attn: workspace too small / misaligned");
         hipStream_t s = (hipStream_t)stream;
-        if (hipMemsetAsync(workspace, 0, attn_ws_bytes(B, n, heads), s) != hipSuccess)
+        if (hipMemsetAsync(workspace, 0, hdr, s) != hipSuccess)
             return uwir_set_error(UWIR_ELAUNCH, "flash_attn: hipMemsetAsync failed");
+        p.kmax2 = (const float*)workspace;
+        p.flags = (int*)workspace + (size_t)B * heads;
+        if (attn_packed_shape(B, n, heads, hd, nv) && workspace_bytes >= attn_packed_bytes(B, n, heads, hd, nv) &&
+            ((uintptr_t)workspace & 255) == 0) {
+            // the pack pre-pass also produces max|k|^2
+            if (hd == 16) return nv == 1 ? launch_attn_packed<16, 1, 2, 2>(p, B, workspace, s)
+                                         : launch_attn_packed<16, 2, 2, 2>(p, B, workspace, s);
+            return nv == 1 ? launch_attn_packed<32, 1, 2, 2>(p, B, workspace, s)
+                           : launch_attn_packed<32, 2, 1, 2>(p, B, workspace, s);
+        }
         hipLaunchKernelGGL(attn_kmax_kernel, dim3(ceil_div(n, KMAX_ROWS), heads, B), dim3(256), 0, s, (const bf16_t*)k, ldk,
                            n, heads, hd, (unsigned*)workspace);
         UWIR_LAUNCH_CHECK("flash_attn(kmax)");
-        p.kmax2 = (const float*)workspace;
-        p.flags = (int*)workspace + (size_t)B * heads;
     }
     if (dtype == UWIR_BF16) return launch_attn<bf16_t>(p, nv, B, (hipStream_t)stream);
     return launch_attn<float>(p, nv, B, (hipStream_t)stream);

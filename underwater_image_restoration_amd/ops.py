@@ -157,14 +157,20 @@ _ATTN_WS = {}
 _NO_FAST = False  # debugging aid (tools/): force the online-max attention loop
 
 
-def _attn_workspace(dev, B: int, n: int, heads: int) -> torch.Tensor:
-    """Small per-device scratch for the bf16 fast path (max_k |k|^2 per (b, head) + block marks); grown on demand."""
-    need = int(_lib.load().uwir_flash_attn_workspace_bytes(B, n, heads))
+_PACKED = True  # tools/: False keeps the workspace at the header size, i.e. the LDS-staged kernels only
+
+
+def _attn_workspace(dev, B: int, n: int, heads: int, hd: int, nv: int):
+    """Per-device scratch for the bf16 fast path, grown on demand: max_k |k|^2 per (b, head) + block marks, and for
+    long hd 16 / 32 sequences the packed K / V^T streams (uwir.h)."""
+    lib = _lib.load()
+    need = int(lib.uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) if _PACKED
+               else lib.uwir_flash_attn_workspace_bytes(B, n, heads))
     t = _ATTN_WS.get(dev)
     if t is None or t.numel() * 4 < need:
         t = torch.empty(max(need // 4, 4096), dtype=torch.float32, device=dev)
         _ATTN_WS[dev] = t
-    return t
+    return t, need  # the library picks its kernels by the byte count it is GIVEN, not by the buffer's capacity
 
 
 def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, o1, o2, fast: bool = True) -> None:
@@ -178,10 +184,11 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    ws = _attn_workspace(q.device, B, n, heads) if (fast and dt == BF16 and not _NO_FAST) else None
+    ws, ws_bytes = (_attn_workspace(q.device, B, n, heads, hd, 1 if v2 is None else 2)
+                    if (fast and dt == BF16 and not _NO_FAST) else (None, 0))
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
                                    0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
-                                   0 if o2 is None else _ld(o2), _dt(o1), _p(ws), 0 if ws is None else ws.numel() * 4,
+                                   0 if o2 is None else _ld(o2), _dt(o1), _p(ws), ws_bytes,
                                    _stream()), "flash_attn")
     if timed:
         ev1.record()
