@@ -261,6 +261,40 @@ size_t uwir_image_metrics_workspace_bytes(int B, int C, int H, int W);
 int uwir_image_metrics(const float* x_nchw, const float* y_nchw, int B, int C, int H, int W, float c1, float c2, float* out,
                        void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
+/* ---- teacher heads: tokens x prompt embeddings -> masks / statistics -> degradation code z_d ----------------------
+ * underwater_ir/teacher/mask_head.py:96-164 (MaskHead.forward), differentiable_crf.py:44-80 (DifferentiableGuidedCRF,
+ * mean-field iterations with a normalised Gaussian and an edge mask from the guidance image) and deg_coder.py:31-59
+ * (DegradationCoder: code = [logit(clamp(global_prob, eps, 1-eps)) | avg_intensity], confidence_scale = 1 - mean_k
+ * confidence).  One launch per call, one block per image.  Maps are NCHW fp32 [B, K, h, w] like the reference's.
+ * tokens: [B*h*w, ld_tokens] rows of C features (token t = y*w + x); text [K, C]; thresholds [K] (device);
+ * image (only with use_crf): NCHW fp32 [B, img_c, img_h, img_w], resized bilinearly (align_corners=False) to (h, w)
+ * when the sizes differ.  K <= 64, crf_ks odd <= 15, morphology_kernel odd (1 = off).
+ * workspace >= uwir_teacher_heads_workspace_bytes(B, h*w, K). */
+typedef struct uwir_teacher_args {
+    const float* tokens;
+    int ld_tokens;
+    const float* text;
+    const float* thresholds;
+    const float* image;
+    int B, h, w, C, K;
+    int img_c, img_h, img_w;
+    float temperature, alpha, confidence_delta, eps;
+    int morphology_kernel;
+    int use_crf, crf_iters, crf_ks;
+    float crf_sigma, crf_edge_weight;
+    float *scores, *probs, *masks, *intensity, *raw_probs; /* [B, K, h, w] */
+    float *avg_intensity, *global_prob, *confidence;       /* [B, K] */
+    float *logits, *code, *confidence_scale;               /* [B, K], [B, 2K], [B] */
+    void* workspace;
+    size_t workspace_bytes;
+} uwir_teacher_args;
+size_t uwir_teacher_heads_workspace_bytes(int B, int n, int K);
+int uwir_teacher_heads(const uwir_teacher_args* args, uwir_stream_t stream);
+/* DifferentiableGuidedCRF.forward(probs, image, confidence=None) on its own: refines probs_in [B, K, h, w] into
+ * args->probs (a different buffer); confidence_in [B, K] or NULL (= 1).  Uses only the shape / image / crf_* /
+ * probs / workspace fields of args. */
+int uwir_guided_crf(const uwir_teacher_args* args, const float* probs_in, const float* confidence_in, uwir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

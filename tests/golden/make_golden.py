@@ -261,10 +261,69 @@ def metrics_case() -> None:
     print("metrics:", {k: float(v) for k, v in store.items() if k.endswith("ssim_loss")})
 
 
+def teacher_inputs(name: str):
+    """Seeded inputs of the teacher-head cases (shared with the tests through tests/golden/cases.py would need torch
+    only; kept here and stored in the .npz because they are tiny)."""
+    g = torch.Generator().manual_seed({"grid7": 51, "crf": 52, "bnc": 53}[name])
+    if name == "grid7":      # ViT-B/32 grid, projected 512-d tokens as (B, C, 7, 7); defaults of MaskHead
+        b, c, h, w, k = 2, 512, 7, 7, 10
+    elif name == "crf":      # non-square grid, CRF on, guidance image at another resolution
+        b, c, h, w, k = 2, 64, 6, 9, 5
+    else:                    # (B, N, C) tokens with N > C, square grid inferred, CRF with a same-size image
+        b, c, h, w, k = 1, 32, 10, 10, 4
+    text = torch.randn(k, c, generator=g)
+    owner = torch.randint(0, k, (b, h, w), generator=g)
+    tok = torch.randn(b, c, h, w, generator=g) + 1.5 * text[owner].permute(0, 3, 1, 2) * torch.rand(b, 1, h, w, generator=g)
+    image = None
+    if name == "crf":
+        image = torch.rand(b, 3, 24, 36, generator=g)
+    elif name == "bnc":
+        image = torch.rand(b, 3, h, w, generator=g)
+        tok = tok.flatten(2).transpose(1, 2).contiguous()
+    return tok, text, image
+
+
+def teacher_case() -> None:
+    """MaskHead / DifferentiableGuidedCRF / DegradationCoder (underwater_ir/teacher/*.py), imported unmodified."""
+    from underwater_ir.teacher import DegradationCoder, DifferentiableGuidedCRF, MaskHead
+    store = {}
+    cfgs = {"grid7": dict(ctor={}, call={}),
+            "crf": dict(ctor=dict(use_crf=True, temperature=6.0, alpha=3.0, crf_iterations=4, crf_spatial_kernel=3,
+                                  crf_spatial_sigma=1.5, crf_edge_weight=4.0, morphology_kernel=3),
+                        call=dict(thresholds=[0.2, 0.3, 0.25, 0.5, 0.15], confidence_delta=0.2)),
+            "bnc": dict(ctor=dict(use_crf=True, morphology_kernel=5, default_threshold=0.3), call={})}
+    for name, cfg in cfgs.items():
+        tok, text, image = teacher_inputs(name)
+        for dt, sfx in ((torch.float32, ""), (torch.float64, "_f64")):
+            head = MaskHead(**cfg["ctor"])
+            with torch.no_grad():
+                out = head(tok.to(dt), text.to(dt), image=None if image is None else image.to(dt), **cfg["call"])
+                code = DegradationCoder()(out, spatial_shape=(3, 4))
+            for f in ("scores", "probs", "masks", "intensity", "avg_intensity", "global_prob", "confidence", "raw_probs"):
+                store[f"{name}_{f}{sfx}"] = getattr(out, f).numpy()
+            for f in ("code", "logits", "confidence_scale"):
+                store[f"{name}_{f}{sfx}"] = getattr(code, f).numpy()
+            assert code.broadcast.shape == (tok.shape[0], 2 * text.shape[0], 3, 4)
+        store[f"{name}_tokens"], store[f"{name}_text"] = tok.numpy(), text.numpy()
+        if image is not None:
+            store[f"{name}_image"] = image.numpy()
+    # the CRF on its own, no confidence weighting
+    g = torch.Generator().manual_seed(54)
+    probs = torch.softmax(torch.randn(2, 4, 8, 8, generator=g) * 2, dim=1)
+    image = torch.rand(2, 3, 8, 8, generator=g)
+    with torch.no_grad():
+        store["crfonly_out_f64"] = DifferentiableGuidedCRF()(probs.double(), image.double()).numpy()
+        store["crfonly_out"] = DifferentiableGuidedCRF()(probs, image).numpy()
+    store["crfonly_probs"], store["crfonly_image"] = probs.numpy(), image.numpy()
+    np.savez_compressed(os.path.join(HERE, "teacher.npz"), **store)
+    print("teacher: mask fill", {n: float(store[f"{n}_masks"].mean()) for n in cfgs},
+          "conf", {n: store[f"{n}_confidence"].mean() for n in cfgs})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics"}
+    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics", "teacher"}
     if "dwt" in which:
         dwt_case()
     if "student" in which:
@@ -280,3 +339,5 @@ if __name__ == "__main__":
             unet_case(name, cfg)
     if "metrics" in which:
         metrics_case()
+    if "teacher" in which:
+        teacher_case()

@@ -32,9 +32,9 @@ def test_version_and_error_channel_work_without_a_gpu():
     assert rc == -1 and b"dwt2" in lib.uwir_last_error()
 
 
-def test_gemm_args_struct_matches_header_field_order():
+def _struct_fields(name):
     text = open(os.path.join(ROOT, "include", "uwir.h")).read()
-    body = text[text.index("typedef struct uwir_gemm_args {"):text.index("} uwir_gemm_args;")]
+    body = text[text.index("typedef struct %s {" % name):text.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in body.split("{", 1)[1].split(";"):
@@ -45,4 +45,9 @@ def test_gemm_args_struct_matches_header_field_order():
         first = names[0].split()[-1].lstrip("*")
         fields.append(first)
         fields += [n.strip().lstrip("*") for n in names[1:]]
-    assert fields == [f[0] for f in _lib.GemmArgs._fields_]
+    return fields
+
+
+def test_arg_structs_match_header_field_order():
+    assert _struct_fields("uwir_gemm_args") == [f[0] for f in _lib.GemmArgs._fields_]
+    assert _struct_fields("uwir_teacher_args") == [f[0] for f in _lib.TeacherArgs._fields_]

@@ -41,6 +41,23 @@ class GemmArgs(C.Structure):
     ]
 
 
+class TeacherArgs(C.Structure):
+    """Mirror of ``struct uwir_teacher_args`` (include/uwir.h) -- field order is ABI."""
+    _fields_ = [
+        ("tokens", vp), ("ld_tokens", ci), ("text", vp), ("thresholds", vp), ("image", vp),
+        ("B", ci), ("h", ci), ("w", ci), ("C", ci), ("K", ci),
+        ("img_c", ci), ("img_h", ci), ("img_w", ci),
+        ("temperature", cf), ("alpha", cf), ("confidence_delta", cf), ("eps", cf),
+        ("morphology_kernel", ci),
+        ("use_crf", ci), ("crf_iters", ci), ("crf_ks", ci),
+        ("crf_sigma", cf), ("crf_edge_weight", cf),
+        ("scores", vp), ("probs", vp), ("masks", vp), ("intensity", vp), ("raw_probs", vp),
+        ("avg_intensity", vp), ("global_prob", vp), ("confidence", vp),
+        ("logits", vp), ("code", vp), ("confidence_scale", vp),
+        ("workspace", vp), ("workspace_bytes", sz),
+    ]
+
+
 _SIGS = {
     "uwir_version": (ci, []),
     "uwir_last_error": (C.c_char_p, []),
@@ -74,6 +91,9 @@ _SIGS = {
     "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_image_metrics_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "uwir_image_metrics": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, sz, vp]),
+    "uwir_teacher_heads_workspace_bytes": (sz, [ci, ci, ci]),
+    "uwir_teacher_heads": (ci, [C.POINTER(TeacherArgs), vp]),
+    "uwir_guided_crf": (ci, [C.POINTER(TeacherArgs), vp, vp, vp]),
     "uwir_add_rows": (ci, [vp, sz, vp, sz, vp, sz, ci, ci, vp]),
     "uwir_patchify": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, sz, vp]),
 }

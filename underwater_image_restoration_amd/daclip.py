@@ -266,5 +266,24 @@ class DaCLIPVision(nn.Module):
             raise NotImplementedError("output_hiddens is only used on the control tower (daclip_model.py:48)")
         return self._main(patches, B, None, control)
 
+    @torch.no_grad()
+    def project_tokens(self, which: str, hidden: torch.Tensor) -> torch.Tensor:
+        """(L, B, width) tokens of tower `which` ("visual" / "control") -> (B, output_dim, g, g): the tower's ln_post and
+        projection (what transformer.py:548-552 applies to the pooled class token) applied to every PATCH token, so
+        that dense tokens can be compared with the prompt embeddings (teacher.daclip_patch_tokens)."""
+        if self._pack is None:
+            self._pack = self._build_pack()
+        t = self._pack["visual_control" if which in ("control", "visual_control") else "visual"]
+        L, B, W = hidden.shape
+        g = self.grid
+        if L != g * g + 1 or W != self.width or not hidden.is_cuda:
+            raise ValueError(f"hidden must be a ROCm tensor of shape ({g * g + 1}, B, {self.width})")
+        rows = hidden[1:].permute(1, 0, 2).reshape(B * g * g, W).float().contiguous()
+        normed = torch.empty_like(rows)
+        ops.ln_rows(rows, t["ln_post"][0], t["ln_post"][1], normed, _EPS)
+        out = torch.empty(B * g * g, self.output_dim, dtype=torch.float32, device=hidden.device)
+        ops.linear(normed, t["proj_t"], None, out)
+        return out.view(B, g, g, self.output_dim).permute(0, 3, 1, 2)
+
     def forward(self, image: torch.Tensor, control: bool = True, normalize: bool = False):
         return self.encode_image(image, control=control, normalize=normalize)
