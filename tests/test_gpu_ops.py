@@ -354,6 +354,17 @@ def test_stem_and_head(ops):
     ops.head_conv3x3(to_rows(feat), b, h, w, 64, asc.cuda(), ash.cuda(), wh.permute(0, 2, 3, 1).contiguous().cuda(), bh.cuda(), 3,
                      x.cuda(), o, pre)
     assert err(pre, pre_ref) < 2e-5 and err(o, pre_ref.clamp(0, 1)) < 2e-5
+    # widths: a multiple of 16 takes the LDS-tiled kernel (maps larger than one 8 x 32 tile, ragged edges), others the
+    # wave-per-pixel form
+    for cin, (hh, ww) in ((48, (19, 70)), (24, (9, 11))):
+        feat = torch.randn(b, cin, hh, ww, generator=g)
+        xr = torch.rand(b, 2, hh, ww, generator=g)
+        wh, bh = torch.randn(2, cin, 3, 3, generator=g) * 0.05, torch.randn(2, generator=g) * 0.1
+        ref = F.conv2d(feat.double(), wh.double(), bh.double(), padding=1) + xr.double()
+        o, pre = torch.empty(b, 2, hh, ww, device="cuda"), torch.empty(b, 2, hh, ww, device="cuda")
+        ops.head_conv3x3(to_rows(feat), b, hh, ww, cin, None, None, wh.permute(0, 2, 3, 1).contiguous().cuda(), bh.cuda(), 2,
+                         xr.cuda(), o, pre)
+        assert err(pre, ref) < 2e-5 and err(o, ref.clamp(0, 1)) < 2e-5, cin
 
 
 def test_sde_steps(ops):
