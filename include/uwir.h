@@ -120,7 +120,13 @@ typedef struct uwir_gemm_args {
                                  Conv2d, module_util.py:100-104); H, W stay the SOURCE size, OH/OW refer to 2H x 2W */
     int batch_ld;             /* row stride of batch_bias / batch_scale (0 = N): lets one [B, total] matrix hold the
                                  per-sample vectors of many layers */
+    void* workspace;          /* optional, 16-byte aligned, >= uwir_conv_gemm_workspace_bytes(args) bytes: lets a plain
+                                 bf16 GEMM with fewer output tiles than CUs (ViT-B/32: 50 tokens x batch rows) cut K
+                                 into slices, one block each, summed in slice order by a second small launch
+                                 (bit-reproducible).  Calls sharing a workspace must be ordered on one stream. */
+    size_t workspace_bytes;
 } uwir_gemm_args;
+size_t uwir_conv_gemm_workspace_bytes(const uwir_gemm_args* args); /* 0 when the launch would not use one */
 int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);
 
 /* ---- multi-scale depthwise conv 3x3 + 5x5 + 7x7 (zero pad) fused with the concat -----------

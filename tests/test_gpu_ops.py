@@ -195,6 +195,34 @@ def test_conv_gemm_spatial(ops, prec):
     assert float(cat[:, co:].min()) == 3.0
 
 
+@pytest.mark.parametrize("shape", [(800, 768, 3072), (800, 768, 768), (130, 200, 1024), (16, 512, 512)])
+def test_conv_gemm_splitk(ops, shape):
+    """Plain bf16 GEMMs with fewer output tiles than CUs cut K into slices (workspace lent by ops.conv_gemm): same
+    result as the single-slice launch up to fp32 summation order, bit-identical run to run (slice-ordered sum, no
+    atomics on data), counters re-armed for the next call."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(31)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    bias, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    ref = A.double() @ Wt.double().T + bias.double() + res.double()
+    outs = []
+    for split in (True, True, False):
+        ops._SPLITK = split
+        try:
+            o = torch.empty(M, N, device="cuda")
+            ops.gemm(A, Wt, o, bias=bias, res=res)
+        finally:
+            ops._SPLITK = True
+        assert err(o, ref) < 2e-4
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[2]).abs().max()) < 1e-4
+    ob = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)      # GELU epilogue on the combined sum, bf16 store
+    ops.gemm(A, Wt, ob, bias=bias, act=ops.ACT_GELU)
+    assert err(ob, torch.nn.functional.gelu(A.double() @ Wt.double().T + bias.double())) < 3e-2
+
+
 def test_conv_gemm_rejects_bad_arguments(ops):
     x = torch.zeros(16, 12, device="cuda")
     w = torch.zeros(8, 12, device="cuda")

@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("batch_scale", vp),
         ("ups", ci),
         ("batch_ld", ci),
+        ("workspace", vp), ("workspace_bytes", sz),
     ]
 
 
@@ -68,6 +69,7 @@ _SIGS = {
     "uwir_affine_cast": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp]),
     "uwir_chan_attn_fold": (ci, [vp, vp, vp, vp, vp, ci, vp]),
     "uwir_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]),
+    "uwir_conv_gemm_workspace_bytes": (sz, [C.POINTER(GemmArgs)]),
     "uwir_conv_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "uwir_dwconv_ms": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     "uwir_flash_attn_workspace_bytes": (sz, [ci, ci, ci]),

@@ -872,7 +872,8 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     int nv = v2 ? 2 : 1;
     p.kmax2 = nullptr;
     p.flags = nullptr;
-    if (dtype == UWIR_BF16 && workspace) {
+    // (short sequences -- ViT towers, 50 tokens -- gain nothing from the bound pre-pass: it would triple their launches)
+    if (dtype == UWIR_BF16 && workspace && n >= 256) {
         const size_t hdr = attn_hdr_bytes(B, n, heads);
         UWIR_CHECK(workspace_bytes >= hdr && ((uintptr_t)workspace & 3) == 0, "flash_attn: workspace too small / misaligned");
         hipStream_t s = (hipStream_t)stream;

@@ -14,8 +14,25 @@
 
 struct GemmP {
     uwir_gemm_args a;
-    int M, K, tiles_n, nblocks;
+    int M, K, tiles_n, nblocks;  // nblocks = output tiles; the grid holds nblocks * splitk blocks
+    int splitk;                  // > 1: K is cut into `splitk` slices, one block each (few-tile launches)
 };
+
+// ---- deterministic split-K.  A launch with fewer output tiles than CUs (DA-CLIP: 800 token rows -> 42 tiles on 256
+// CUs, 48 K tiles each) is bound by the per-K-tile load latency of its few blocks.  Each slice block dumps its fp32
+// accumulators to the caller's workspace ([slice][tile][reg][thread] float4: coalesced) and a second small launch adds
+// the slices IN SLICE ORDER (bit-reproducible, unlike atomics) and runs the epilogue.  Two launches rather than a
+// "last block combines" scheme: cross-block hand-over inside one kernel needs agent-scope release / acquire, which
+// on this multi-XCD part writes back and invalidates whole L2s (measured 2x slower than not splitting at all).
+#define SPLITK_MAX 8
+template <int TM, int TN>
+__device__ __forceinline__ void splitk_dump(const GemmP& p, const f32x4 (&acc)[TM][TN], int tile, int slice) {
+    f32x4* mine = (f32x4*)p.a.workspace + ((size_t)slice * p.nblocks + tile) * ((size_t)TM * TN * 256);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mine[(size_t)(i * TN + j) * 256 + threadIdx.x] = acc[i][j];
+}
 
 template <typename T> struct MmaCfg;
 template <> struct MmaCfg<bf16_t> {
@@ -375,8 +392,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     const uwir_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    {
+    int bid = blockIdx.x, slice = 0;
+    if (p.splitk > 1) {
+        slice = bid % p.splitk;
+        bid /= p.splitk;
+    } else {
         int nwg = p.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
@@ -446,24 +466,60 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     };
+    int kt0 = 0, kt1 = nk;
+    if (p.splitk > 1) {
+        kt0 = (int)((long long)nk * slice / p.splitk);
+        kt1 = (int)((long long)nk * (slice + 1) / p.splitk);
+    }
     if constexpr (NBUF == 2) {
-        stage(0, 0);
+        stage(0, kt0);
         __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) stage(buf ^ 1, kt + 1);
             compute(buf);
             __syncthreads();
         }
     } else {
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < kt1; ++kt) {
             stage(0, kt);
             __syncthreads();
             compute(0);
             __syncthreads();
         }
     }
+    if (p.splitk > 1) {
+        splitk_dump<TM, TN>(p, acc, bid, slice);
+        return;
+    }
     gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
+}
+
+// second launch of a split-K GEMM: one block per (output tile, 16-row MFMA group i), same thread <-> element mapping as
+// the glds kernel; 4 x splitk independent 16-byte loads per thread
+__global__ void __launch_bounds__(256) gemm_splitk_epilogue_kernel(GemmP p) {
+    constexpr int TM = 4, TN = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x >> 2, i = blockIdx.x & 3;
+    const int m0 = (tile / p.tiles_n) * 128, n0 = (tile % p.tiles_n) * 128;
+    const f32x4* part = (const f32x4*)p.a.workspace;
+    const size_t per_tile = (size_t)TM * TN * 256;
+    f32x4 v[SPLITK_MAX][TN];
+#pragma unroll
+    for (int sl = 0; sl < SPLITK_MAX; ++sl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            v[sl][j] = sl < p.splitk ? part[((size_t)sl * p.nblocks + tile) * per_tile + (size_t)(i * TN + j) * 256 + tid]
+                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 sum = v[0][j];
+#pragma unroll
+        for (int sl = 1; sl < SPLITK_MAX; ++sl) sum += v[sl][j];  // slice order; absent slices add +0
+        acc[0][j] = sum;
+    }
+    gemm_epilogue<1, TN>(p.a, acc, p.M, m0 + (wave >> 1) * 64 + i * 16, n0 + (wave & 1) * 64, lane & 15, lane >> 4);
 }
 
 static bool glds_eligible(const uwir_gemm_args& g, int K) {
@@ -471,6 +527,24 @@ static bool glds_eligible(const uwir_gemm_args& g, int K) {
            !g.a_scale && K % 64 == 0 && g.N > 64 && g.lda % 8 == 0 && !g.ups;
 }
 
+
+// split-K factor of a plain bf16 GEMM with 128 x 128 tiles (1 = none) and the workspace it needs
+static int splitk_want(int M, int N, int K) {
+    const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128);
+    if (tiles >= 128) return 1;
+    int s = (int)(256 / tiles);
+    s = s < K / 64 / 3 ? s : K / 64 / 3;  // at least 3 K tiles per slice
+    return s > SPLITK_MAX ? SPLITK_MAX : (s < 1 ? 1 : s);
+}
+static size_t splitk_bytes(int M, int N, int s) {
+    return (size_t)s * ceil_div(M, 128) * ceil_div(N, 128) * (128 * 128 * sizeof(float));
+}
+static int splitk_factor(int M, int N, int K, const void* ws, size_t ws_bytes) {
+    int s = splitk_want(M, N, K);
+    if (s <= 1 || !ws || ((uintptr_t)ws & 15) != 0) return 1;
+    while (s > 1 && splitk_bytes(M, N, s) > ws_bytes) --s;
+    return s;
+}
 
 template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
@@ -482,6 +556,15 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     long long nb = (long long)ceil_div(p.M, 128) * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
+    if (glds_eligible(p.a, p.K) && p.nblocks < 256) {
+        // fewer tiles than CUs: per-tile latency is what matters.  Double-buffered staging (57 -> 44 us at M800 N768
+        // K3072) and, when the caller lent a workspace, split-K (see splitk_dump)
+        p.splitk = splitk_factor(p.M, p.a.N, p.K, p.a.workspace, p.a.workspace_bytes);
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<2>, dim3(p.nblocks * p.splitk), dim3(256), 0, stream, p);
+        if (p.splitk > 1) hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3(p.nblocks * 4), dim3(256), 0, stream, p);
+        UWIR_LAUNCH_CHECK("conv_gemm(glds, few tiles)");
+        return UWIR_OK;
+    }
     if (glds_eligible(p.a, p.K)) {
         // measured on MI355X (tools/bench_gemm.py): the single-buffered form wins at every K of this path, e.g.
         // M262144 N384: K192 0.155 -> 0.124 ms, K768 0.303 -> 0.256; M262144 N576 K1728 0.796 -> 0.689;
@@ -498,6 +581,17 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
         hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 128, 1>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm");
     return UWIR_OK;
+}
+
+extern "C" size_t uwir_conv_gemm_workspace_bytes(const uwir_gemm_args* args) {
+    if (!args) return 0;
+    const uwir_gemm_args& g = *args;
+    if (g.B <= 0 || g.OH <= 0 || g.OW <= 0 || g.C <= 0 || g.N <= 0) return 0;
+    const long long M = (long long)g.B * g.OH * g.OW;
+    const int K = g.KH * g.KW * g.C;
+    if (M >= 0x7fffffffLL || !glds_eligible(g, K)) return 0;
+    const int s = splitk_want((int)M, g.N, K);
+    return s > 1 ? splitk_bytes((int)M, g.N, s) : 0;
 }
 
 extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) {
@@ -545,6 +639,7 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.K = g.KH * g.KW * g.C;
     p.tiles_n = 0;
     p.nblocks = 0;
+    p.splitk = 1;
     hipStream_t s = (hipStream_t)stream;
     if (g.compute == UWIR_BF16) {
         if (g.a_dtype == UWIR_F32) return launch_gemm<bf16_t, float>(p, s);

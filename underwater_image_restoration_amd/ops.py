@@ -102,6 +102,10 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], y: to
     _lib.check(lib.uwir_linear(_p(x), _ld(x), B, I, _p(W), _p(bias), O, act, _p(y), _ld(y), _stream()), "linear")
 
 
+_GEMM_WS = {}    # per-device split-K scratch (stream-ordered reuse; see uwir_gemm_args.workspace)
+_SPLITK = True   # tools/: False = never lend the scratch
+
+
 def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *, B: int, H: int, W: int, C_: int,
               N: int, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, OH: Optional[int] = None,
               OW: Optional[int] = None, a_scale=None, a_shift=None, bias=None, batch_bias=None, act: int = ACT_NONE,
@@ -140,6 +144,14 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
     g.compute = _dt(Wt)
     g.col_scale = _p(col_scale)
     g.batch_scale, g.ups = _p(batch_scale), ups
+    if _SPLITK and -(-(B * g.OH * g.OW) // 128) * -(-N // 128) < 128 and KH == 1 and g.a_dtype == BF16:
+        need = int(lib.uwir_conv_gemm_workspace_bytes(C.byref(g)))   # few output tiles: lend the split-K scratch
+        if need:
+            ws = _GEMM_WS.get(A.device)
+            if ws is None or ws.numel() * 4 < need:
+                ws = torch.zeros(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=A.device)  # counters start at 0
+                _GEMM_WS[A.device] = ws
+            g.workspace, g.workspace_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
 
 
