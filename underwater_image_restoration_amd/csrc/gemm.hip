@@ -58,9 +58,20 @@ __device__ __forceinline__ int chan_perm(int rho) {
 
 // ---- shared epilogue: the lane holds, per (i, j) MFMA tile, pixel m = m_base + i*16 + fr and the 4
 //      consecutive channels n = n_base + fq*16 + j*4 .. +3
+// mrow[i] = output row (pixel index (b*OH + oy)*OW + ox) of the FIRST of the 16 pixels of MFMA tile i, mcnt[i] = how many
+// of the 16 exist (<= 0: none): linear M tiles pass consecutive runs, spatial tiles one image row segment each.
+template <int TM>
+__device__ __forceinline__ void linear_rows(int (&mrow)[TM], int (&mcnt)[TM], int m_base, int M) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        mrow[i] = m_base + i * 16;
+        mcnt[i] = M - mrow[i];
+    }
+}
+
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], int M, int m_base,
-                                              int n_base, int fr, int fq) {
+__device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], const int (&mrow)[TM],
+                                              const int (&mcnt)[TM], int n_base, int fr, int fq) {
     static_assert(TN == 4, "the channel permutation assumes 4 MFMA tiles per 64-channel wave block");
     const int N = g.N;
     const int OHW = g.OH * g.OW;
@@ -68,8 +79,8 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
     const int bld = g.batch_ld ? g.batch_ld : N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        int m = m_base + i * 16 + fr;
-        if (m >= M) continue;
+        if (fr >= mcnt[i]) continue;
+        int m = mrow[i] + fr;
         int b = m / OHW;
         size_t out_row = (size_t)m;
         int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
@@ -369,7 +380,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
         }
     }
 
-    gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
+    int mrow[TM], mcnt[TM];
+    linear_rows<TM>(mrow, mcnt, m0 + wm0, M);
+    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,7 +505,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
         splitk_dump<TM, TN>(p, acc, bid, slice);
         return;
     }
-    gemm_epilogue<TM, TN>(g, acc, M, m0 + wm0, n0 + wn0, fr, fq);
+    int mrow[TM], mcnt[TM];
+    linear_rows<TM>(mrow, mcnt, m0 + wm0, M);
+    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
 }
 
 // second launch of a split-K GEMM: one block per (output tile, 16-row MFMA group i), same thread <-> element mapping as
@@ -519,7 +534,9 @@ __global__ void __launch_bounds__(256) gemm_splitk_epilogue_kernel(GemmP p) {
         for (int sl = 1; sl < SPLITK_MAX; ++sl) sum += v[sl][j];  // slice order; absent slices add +0
         acc[0][j] = sum;
     }
-    gemm_epilogue<1, TN>(p.a, acc, p.M, m0 + (wave >> 1) * 64 + i * 16, n0 + (wave & 1) * 64, lane & 15, lane >> 4);
+    int mrow[1], mcnt[1];
+    linear_rows<1>(mrow, mcnt, m0 + (wave >> 1) * 64 + i * 16, p.M);
+    gemm_epilogue<1, TN>(p.a, acc, mrow, mcnt, n0 + (wave & 1) * 64, lane & 15, lane >> 4);
 }
 
 static bool glds_eligible(const uwir_gemm_args& g, int K) {
@@ -527,6 +544,215 @@ static bool glds_eligible(const uwir_gemm_args& g, int K) {
            !g.a_scale && K % 64 == 0 && g.N > 64 && g.lda % 8 == 0 && !g.ups;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (the IR-SDE UNet's ResBlocks: 236 of its 266 GF per step) as an implicit GEMM over
+// LDS-staged HALO tiles.  The generic kernel above gathers an im2col K tile per filter tap, i.e. it pulls every input
+// pixel through L2 -> registers -> (convert) -> LDS nine times; at N = 64 that traffic, not the MFMA, bounds it.  Here
+// a block owns an 8 x 16 pixel output tile: per 32-channel chunk the (8+2) x (16+2) input tile is staged ONCE (affine +
+// bf16 conversion on the way in, zero padding, nearest-2x upsampling by source addressing), and the nine taps are nine
+// shifted views of it: the B operand of tap (ky, kx) for pixel (y, x) is LDS row (y+ky)*18 + x+kx.  Weights stream
+// through LDS three taps (one filter row) at a time.  Register prefetch of the next stage overlaps the MFMAs.
+// ------------------------------------------------------------------------------------------
+#define HC_TH 8
+#define HC_TW 16
+#define HC_PW (HC_TW + 2)
+#define HC_NPIX ((HC_TH + 2) * HC_PW)   // 180
+#define HC_BK 32
+#define HC_STR 40                        // LDS row stride in bf16 (32 + 8 pad): conflict-free 16-byte fragment reads
+#define HC_TG 3                          // taps per weight stage
+
+template <typename TA, int BN>
+__global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
+    constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N, TM = HC_TH / WAVES_M, TN = 4;
+    constexpr int A_ITEMS = HC_NPIX * (HC_BK / 8);                    // 16-byte (8 x bf16) pieces of the halo tile
+    constexpr int A_IT = (A_ITEMS + 255) / 256;
+    constexpr int W_ITEMS = HC_TG * BN * (HC_BK / 8);
+    constexpr int W_IT = (W_ITEMS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[HC_NPIX * HC_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[HC_TG * BN * HC_STR];
+
+    const uwir_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    {
+        int nwg = p.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int OH = g.OH, OW = g.OW, C = g.C, N = g.N, K = p.K;
+    const int tiles_x = (OW + HC_TW - 1) / HC_TW, tiles_y = (OH + HC_TH - 1) / HC_TH;
+    const int n0 = (bid % p.tiles_n) * BN;
+    int mt = bid / p.tiles_n;
+    const int tx = mt % tiles_x; mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int b = mt / tiles_y;
+    const int y0 = ty * HC_TH, x0 = tx * HC_TW;
+    const TA* __restrict__ Aptr = (const TA*)g.A;
+    const bf16_t* __restrict__ Wptr = (const bf16_t*)g.Wt;
+
+    // ---- per-thread staging descriptors of the halo tile (fixed over the chunk loop): source pixel offset or -1
+    long long a_off[A_IT];
+    int a_ch[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int item = tid + 256 * it;
+        const int pix = item / (HC_BK / 8), piece = item % (HC_BK / 8);
+        const int iy = y0 + pix / HC_PW - 1, ix = x0 + pix % HC_PW - 1;   // coordinates in the (upsampled) input image
+        const bool ok = item < A_ITEMS && iy >= 0 && iy < OH && ix >= 0 && ix < OW;
+        a_off[it] = ok ? (((long long)b * g.H + (iy >> g.ups)) * g.W + (ix >> g.ups)) * g.lda + piece * 8 : -1;
+        a_ch[it] = piece * 8;
+    }
+    RawChunk<TA, 8> ra[A_IT];
+    bf16x8 rw[W_IT];
+
+    const int nchunks = C / HC_BK;
+    const int nstages = nchunks * (9 / HC_TG);
+    auto load_stage = [&](int st) {
+        const int chunk = st / (9 / HC_TG), grp = st % (9 / HC_TG);
+        const int c0 = chunk * HC_BK;
+        if (grp == 0) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                if (a_off[it] >= 0) {
+                    const TA* src = Aptr + a_off[it] + c0;
+                    if constexpr (sizeof(TA) == 4) {
+                        ra[it].lo = *reinterpret_cast<const float4*>(src);
+                        ra[it].hi = *reinterpret_cast<const float4*>(src + 4);
+                    } else {
+                        ra[it].v = *reinterpret_cast<const bf16x8*>(src);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int item = tid + 256 * it;
+            const int row = item / (HC_BK / 8), piece = item % (HC_BK / 8);   // row = tap_local * BN + channel
+            const int tapl = row / BN, nn = n0 + row % BN;
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+            if (item < W_ITEMS && nn < N)
+                z = *reinterpret_cast<const bf16x8*>(Wptr + (size_t)nn * K + (size_t)(grp * HC_TG + tapl) * C + c0 + piece * 8);
+            rw[it] = z;
+        }
+    };
+    auto store_stage = [&](int st) {
+        const int chunk = st / (9 / HC_TG), grp = st % (9 / HC_TG);
+        const int c0 = chunk * HC_BK;
+        if (grp == 0) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int item = tid + 256 * it;
+                if (item >= A_ITEMS) continue;
+                const int pix = item / (HC_BK / 8);
+                bf16x8 o;
+                if (a_off[it] >= 0) {
+                    float v[8];
+                    if constexpr (sizeof(TA) == 4) {
+                        v[0] = ra[it].lo.x; v[1] = ra[it].lo.y; v[2] = ra[it].lo.z; v[3] = ra[it].lo.w;
+                        v[4] = ra[it].hi.x; v[5] = ra[it].hi.y; v[6] = ra[it].hi.z; v[7] = ra[it].hi.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (float)ra[it].v[j];
+                    }
+                    if (g.a_scale) {
+                        const float* sc = g.a_scale + (size_t)b * C + c0 + a_ch[it];
+                        const float* sh = g.a_shift + (size_t)b * C + c0 + a_ch[it];
+#pragma unroll
+                        for (int j = 0; j < 8; j += 4) {
+                            float4 s4 = load4(sc + j), h4 = load4(sh + j);
+                            v[j] = fmaf(v[j], s4.x, h4.x);
+                            v[j + 1] = fmaf(v[j + 1], s4.y, h4.y);
+                            v[j + 2] = fmaf(v[j + 2], s4.z, h4.z);
+                            v[j + 3] = fmaf(v[j + 3], s4.w, h4.w);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(&sA[pix * HC_STR + a_ch[it]]) = o;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int item = tid + 256 * it;
+            if (item >= W_ITEMS) continue;
+            const int row = item / (HC_BK / 8), piece = item % (HC_BK / 8);
+            const int tapl = row / BN, nl = row % BN;
+            *reinterpret_cast<bf16x8*>(&sW[(tapl * BN + chan_perm(nl)) * HC_STR + piece * 8]) = rw[it];  // LDS row pi(n)
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wr0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * 64;   // first output row / channel of this wave
+
+    auto compute = [&](int st) {
+        const int grp = st % (9 / HC_TG);   // taps grp*3 .. grp*3+2 = filter row ky = grp, kx = 0..2
+#pragma unroll
+        for (int tapl = 0; tapl < HC_TG; ++tapl) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(&sA[((wr0 + i + grp) * HC_PW + fr + tapl) * HC_STR + fq * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(&sW[(tapl * BN + wn0 + j * 16 + fr) * HC_STR + fq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_stage(0);
+    for (int st = 0; st < nstages; ++st) {
+        if (st) __syncthreads();          // every wave is done with the previous stage's LDS image
+        store_stage(st);
+        __syncthreads();
+        if (st + 1 < nstages) load_stage(st + 1);
+        compute(st);
+    }
+
+    int mrow[TM], mcnt[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oy = y0 + wr0 + i;
+        mrow[i] = (b * OH + oy) * OW + x0;
+        mcnt[i] = oy < OH ? OW - x0 : 0;
+    }
+    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
+}
+
+static bool halo_eligible(const uwir_gemm_args& g) {
+    return g.compute == UWIR_BF16 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.C % HC_BK == 0 &&
+           g.OH == (g.H << g.ups) && g.OW == (g.W << g.ups) && g.lda % 8 == 0;
+}
+
+template <typename TA>
+static int launch_halo(const GemmP& p0, hipStream_t stream) {
+    GemmP p = p0;
+    const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, HC_TH) * ceil_div(p.a.OW, HC_TW);
+    int bn = p.a.N <= 64 ? 64 : 128;
+    if (bn == 128 && mtiles * ceil_div(p.a.N, 128) < 512) bn = 64;
+    p.tiles_n = ceil_div(p.a.N, bn);
+    const long long nb = mtiles * p.tiles_n;
+    if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
+    p.nblocks = (int)nb;
+    if (bn == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 128>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    UWIR_LAUNCH_CHECK("conv_gemm(halo)");
+    return UWIR_OK;
+}
 
 // split-K factor of a plain bf16 GEMM with 128 x 128 tiles (1 = none) and the workspace it needs
 static int splitk_want(int M, int N, int K) {
@@ -641,6 +867,10 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.nblocks = 0;
     p.splitk = 1;
     hipStream_t s = (hipStream_t)stream;
+    if (halo_eligible(g)) {
+        if (g.a_dtype == UWIR_F32) return launch_halo<float>(p, s);
+        if (g.a_dtype == UWIR_BF16) return launch_halo<bf16_t>(p, s);
+    }
     if (g.compute == UWIR_BF16) {
         if (g.a_dtype == UWIR_F32) return launch_gemm<bf16_t, float>(p, s);
         if (g.a_dtype == UWIR_BF16) return launch_gemm<bf16_t, bf16_t>(p, s);
