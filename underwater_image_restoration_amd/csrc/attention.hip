@@ -515,50 +515,46 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
                                                         int heads, bf16_t* __restrict__ Kp, bf16_t* __restrict__ Vtp,
                                                         unsigned* __restrict__ kmax2) {
     using P = PackCfg<HD, NV>;
-    constexpr int DV = P::DV, ROWS = P::ROWS, SV = DV + 2;  // LDS row stride (elements): odd dword count
-    __shared__ bf16_t sV[PK_KEYS * SV];
+    constexpr int DV = P::DV, ROWS = P::ROWS, SV = DV + 8;  // LDS row stride (elements): rows stay 16-byte aligned
+    constexpr int PPK = HD / 8;                             // 16-byte pieces per key row
+    __shared__ __attribute__((aligned(16))) bf16_t sV[PK_KEYS * SV];
     const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int bh = b * heads + head;
-    const int k0 = blockIdx.x * PK_KEYS, key = k0 + tid;
+    const int k0 = blockIdx.x * PK_KEYS;
     float m = 0.f;
-    if (key < npad) {
-        bf16_t* kd = Kp + ((size_t)bh * npad + key) * HD;
+    // ---- phase 1: 16-byte pieces, adjacent lanes = adjacent pieces of one key row (K straight to its packed place,
+    //      V rows into LDS for the transposition)
+#pragma unroll
+    for (int it = 0; it < PK_KEYS * PPK / 256; ++it) {
+        const int idx = tid + 256 * it;
+        const int kl = idx / PPK, piece = idx % PPK, key = k0 + kl;
+        bf16x8 kv, vv[NV];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = (bf16_t)0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) vv[t] = kv;
         if (key < n) {
             const size_t r = (size_t)b * n + key;
-            const bf16_t* kr = k + r * ldk + (size_t)head * HD;
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                bf16x4 t = *reinterpret_cast<const bf16x4*>(kr + d);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float f = (float)t[e]; s = fmaf(f, f, s); }
-                *reinterpret_cast<bf16x4*>(kd + d) = t;
-            }
-            m = s;
-#pragma unroll
-            for (int vv = 0; vv < NV; ++vv) {
-                const bf16_t* vr = (vv == 0 ? v1 + r * ldv1 : v2 + r * ldv2) + (size_t)head * HD;
-#pragma unroll
-                for (int d = 0; d < HD; d += 4) {
-                    bf16x4 t = *reinterpret_cast<const bf16x4*>(vr + d);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sV[tid * SV + vv * HD + d + e] = t[e];
-                }
-            }
-        } else {
-            bf16x4 z;
-            z[0] = z[1] = z[2] = z[3] = (bf16_t)0.f;
-#pragma unroll
-            for (int d = 0; d < HD; d += 4) *reinterpret_cast<bf16x4*>(kd + d) = z;
-#pragma unroll
-            for (int d = 0; d < DV; ++d) sV[tid * SV + d] = (bf16_t)0.f;
+            kv = *reinterpret_cast<const bf16x8*>(k + r * ldk + (size_t)head * HD + piece * 8);
+            vv[0] = *reinterpret_cast<const bf16x8*>(v1 + r * ldv1 + (size_t)head * HD + piece * 8);
+            if constexpr (NV > 1) vv[1] = *reinterpret_cast<const bf16x8*>(v2 + r * ldv2 + (size_t)head * HD + piece * 8);
         }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float f = (float)kv[e]; s = fmaf(f, f, s); }
+#pragma unroll
+        for (int off = 1; off < PPK; off <<= 1) s += __shfl_xor(s, off);   // the PPK lanes of one key
+        m = fmaxf(m, s);
+        if (key < npad) *reinterpret_cast<bf16x8*>(Kp + ((size_t)bh * npad + key) * HD + piece * 8) = kv;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) *reinterpret_cast<bf16x8*>(&sV[kl * SV + t * HD + piece * 8]) = vv[t];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if ((tid & 63) == 0 && m > 0.f) atomicMax(kmax2 + bh, __float_as_uint(m));
     __syncthreads();
-    // one item = one V^T row of one 16-key group: 16 keys gathered in accumulator order, one 32-byte store
+    // ---- phase 2: one item = one V^T row of one 16-key group: 16 keys gathered in accumulator order, one 32-byte
+    //      store; adjacent lanes = adjacent rows, so a key group's ROWS x 32 bytes leave as one contiguous run
     for (int item = tid; item < (PK_KEYS / 16) * ROWS; item += 256) {
         const int kg = item / ROWS, row = item - kg * ROWS;
         const int kbase = k0 + kg * 16;
