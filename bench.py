@@ -154,7 +154,7 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.event_timing(True)  # HIP events around the dominant kernel's launches only (flash attention)
+    ops.event_timing(True)  # HIP events around the main kernel of every flash-attention call (uwir_flash_attn_probe)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -177,7 +177,7 @@ def main() -> None:
         dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
         roof = None
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
+        tj = os.path.join(ROOT, "profiles", "r1_v3_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
         if os.path.exists(tj) and args.batch == 16 and args.size == 256 and args.precision == "bf16":
             with open(tj) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -186,7 +186,8 @@ def main() -> None:
             fl = 4.0 * args.batch * 12 * float(n0) ** 2 * (args.size and 16)  # 4*B*heads*n^2*hd
             ach = fl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            roof = {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd16,1V> (WTB level 0; kmax pre-pass + fast + online-max launches)", "achieved": round(ach, 2),
+            roof = {"bound": "mfma", "kernel": "attn_stream_kernel<hd16,1V,QG2> (WTB level-0 attention, main launch only: HIP events armed "
+                              "through uwir_flash_attn_probe on the launch stream)", "achieved": round(ach, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}
         cpu = None

@@ -152,6 +152,10 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * hd 16 or 32 (n >= 2048, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
  * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier.  The
  * results are the same function of the inputs to bf16 rounding; shapes outside that range return the small size. */
+/* Measurement hook with no counterpart in the reference: arms two hipEvent_t for the NEXT uwir_flash_attn call of the
+ * calling thread; they are recorded on that call's stream right before / after the launch of its main kernel only
+ * (not the pre-pass, not the fallback launch), so a benchmark can time the dominant kernel in place. */
+int uwir_flash_attn_probe(void* hip_event_before, void* hip_event_after);
 size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads);
 size_t uwir_flash_attn_packed_workspace_bytes(int B, int n, int heads, int hd, int nv);
 int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v1, int ldv1, const void* v2,

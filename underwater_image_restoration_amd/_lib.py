@@ -72,6 +72,7 @@ _SIGS = {
     "uwir_conv_gemm_workspace_bytes": (sz, [C.POINTER(GemmArgs)]),
     "uwir_conv_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "uwir_dwconv_ms": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "uwir_flash_attn_probe": (ci, [vp, vp]),
     "uwir_flash_attn_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_flash_attn_packed_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "uwir_flash_attn": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, vp, ci, vp, ci, ci, vp, sz, vp]),

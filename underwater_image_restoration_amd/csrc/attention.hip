@@ -781,6 +781,22 @@ static size_t attn_packed_bytes(int B, int n, int heads, int hd, int nv) {
     return pk_align256(attn_hdr_bytes(B, n, heads)) + pk_align256(bh * npad * hd * 2) + pk_align256(bh * (npad / 16) * rows * 32);
 }
 
+// Measurement hook (bench.py's roofline leg): a pair of HIP events armed for the NEXT uwir_flash_attn call of this
+// thread is recorded immediately before and after the launch of the call's MAIN kernel only (not the pack / bound
+// pre-pass, not the fallback launch), on the call's stream.  Thread-local like the error string; cleared by use.
+static thread_local hipEvent_t g_probe[2] = {nullptr, nullptr};
+extern "C" int uwir_flash_attn_probe(void* ev_before, void* ev_after) {
+    g_probe[0] = (hipEvent_t)ev_before;
+    g_probe[1] = (hipEvent_t)ev_after;
+    return UWIR_OK;
+}
+static inline void probe_mark(int which, hipStream_t stream) {
+    if (g_probe[which]) {
+        (void)hipEventRecord(g_probe[which], stream);
+        g_probe[which] = nullptr;
+    }
+}
+
 template <int HD, int NV, int QG, int PF>
 static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_t stream) {
     using P = PackCfg<HD, NV>;
@@ -798,8 +814,10 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
     const int nqb = ceil_div(n, 128 * QG);
     const long long nb = (long long)nqb * p.heads * B;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "flash_attn: grid too large");
+    probe_mark(0, stream);
     hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF>), dim3((unsigned)nb), dim3(256), 0, stream, p, Kp, Vtp, npad, nqb,
                        (int)nb);
+    probe_mark(1, stream);
     // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
     hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, QG, 2>), dim3(nqb, p.heads, B), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("flash_attn(stream)");
@@ -813,15 +831,19 @@ static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
         // (the two-V variant measured no faster this way -- 202 VGPRs, 2 waves/SIMD -- and stays on the single launch)
         if (nv == 1 && p.flags && (long long)ceil_div(p.n, 256) * p.heads * B >= 1024) {
             dim3 grid(ceil_div(p.n, 256), p.heads, B);
+            probe_mark(0, stream);
             hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 2, 1>), grid, dim3(256), 0, stream, p);
+            probe_mark(1, stream);
             hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 2, 2>), grid, dim3(256), 0, stream, p);
             UWIR_LAUNCH_CHECK("flash_attn(split)");
             return UWIR_OK;
         }
     }
     dim3 grid(ceil_div(p.n, 128), p.heads, B);
+    probe_mark(0, stream);
     if (nv == 1) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 1, 0>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2, 1, 0>), grid, dim3(256), 0, stream, p);
+    probe_mark(1, stream);
     UWIR_LAUNCH_CHECK("flash_attn");
     return UWIR_OK;
 }

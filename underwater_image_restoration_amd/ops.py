@@ -193,9 +193,11 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
     if o2 is not None and _dt(o2) != _dt(o1):
         raise TypeError("flash_attn: outputs must share a dtype")
     timed = _TIMING["on"]
-    if timed:
+    if timed:   # events around the call's MAIN kernel only, recorded by the library on the launch stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+        ev1.record()   # (creates the underlying hipEvent_t handles)
+        lib.uwir_flash_attn_probe(ev0.cuda_event, ev1.cuda_event)
     ws, ws_bytes = (_attn_workspace(q.device, B, n, heads, hd, 1 if v2 is None else 2)
                     if (fast and dt == BF16 and not _NO_FAST) else (None, 0))
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
@@ -203,7 +205,6 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
                                    0 if o2 is None else _ld(o2), _dt(o1), _p(ws), ws_bytes,
                                    _stream()), "flash_attn")
     if timed:
-        ev1.record()
         _TIMING["events"].append((("flash_attn", B, n, heads, hd, 1 if v2 is None else 2, dt), ev0, ev1))
 
 
