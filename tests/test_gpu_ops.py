@@ -233,7 +233,7 @@ def test_conv_gemm_rejects_bad_arguments(ops):
 
 
 @pytest.mark.parametrize("io", [("fp32", "fp32"), ("fp32", "bf16"), ("bf16", "bf16")])
-@pytest.mark.parametrize("shape", [(2, 48, 9, 21), (1, 576, 16, 16), (1, 20, 3, 2), (2, 64, 40, 8)])
+@pytest.mark.parametrize("shape", [(2, 48, 9, 21), (1, 576, 16, 16), (1, 20, 3, 2), (2, 64, 40, 8), (1, 40, 17, 33)])
 def test_dwconv_ms(ops, io, shape):
     b, c, h, w = shape
     g = torch.Generator().manual_seed(6)
