@@ -131,43 +131,55 @@ extern "C" int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf
 // Pass 2: one thread per (b,c) combines partials in a FIXED order (deterministic) in fp64 and
 //         emits the folded affine a*x + s.
 // ------------------------------------------------------------------------------------------
-#define LN_ROWS_PER_BLOCK 256
+#define LN_ROWS_PER_BLOCK 128
 #define LN_SLAB_Q 64  // channel quads per block (256 channels)
 
 __global__ void __launch_bounds__(256) ln_partial_kernel(const float* __restrict__ x, int ldx, int n, int C4,
                                                          double* __restrict__ part, int nchunks) {
-    // threads: tx = quad within slab (0..qs-1), ty = row lane
+    // threads: tx = quad within the slab (0..qs-1), ty = row lane (0..rl-1); rl = 256 / qs uses (nearly) every thread
+    // whatever the width (C = 192: 48 quads x 5 row lanes), 4 independent 16-byte loads in flight per thread
     const int qs = min(C4 - blockIdx.y * LN_SLAB_Q, LN_SLAB_Q);
-    const int rl = 256 / LN_SLAB_Q;  // 4 row lanes when slab is full
-    const int tx = threadIdx.x % LN_SLAB_Q, ty = threadIdx.x / LN_SLAB_Q;
+    const int rl = 256 / qs;
+    const int tx = threadIdx.x % qs, ty = threadIdx.x / qs;
     const int b = blockIdx.z, chunk = blockIdx.x;
     const int q = blockIdx.y * LN_SLAB_Q + tx;
-    __shared__ float red[2][4][LN_SLAB_Q][4];  // [sum|sq][row lane][quad][4]
+    __shared__ float red[2][256][4];  // [sum|sq][ty * qs + tx][4]
     float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
-    if (tx < qs) {
+    const bool active = ty < rl;
+    if (active) {
         const float* base = x + (size_t)b * n * ldx + 4 * q;
-        float4 K = load4(base);
-        int r0 = chunk * LN_ROWS_PER_BLOCK, r1 = min(n, r0 + LN_ROWS_PER_BLOCK);
-        for (int r = r0 + ty; r < r1; r += rl) {
-            float4 v = load4(base + (size_t)r * ldx);
-            float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
-            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
-            ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
-        }
+        const float4 K = load4(base);
+        const int r0 = chunk * LN_ROWS_PER_BLOCK, r1 = min(n, r0 + LN_ROWS_PER_BLOCK);
+#define LN_ACC(v)                                                                   \
+    {                                                                               \
+        float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;       \
+        s.x += dx; s.y += dy; s.z += dz; s.w += dw;                                 \
+        ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;         \
     }
-    *reinterpret_cast<float4*>(red[0][ty][tx]) = s;
-    *reinterpret_cast<float4*>(red[1][ty][tx]) = ss;
+        int r = r0 + ty;
+        for (; r + 3 * rl < r1; r += 4 * rl) {
+            const float4 v0 = load4(base + (size_t)r * ldx), v1 = load4(base + (size_t)(r + rl) * ldx);
+            const float4 v2 = load4(base + (size_t)(r + 2 * rl) * ldx), v3 = load4(base + (size_t)(r + 3 * rl) * ldx);
+            LN_ACC(v0) LN_ACC(v1) LN_ACC(v2) LN_ACC(v3)
+        }
+        for (; r < r1; r += rl) {
+            const float4 v = load4(base + (size_t)r * ldx);
+            LN_ACC(v)
+        }
+#undef LN_ACC
+        *reinterpret_cast<float4*>(red[0][ty * qs + tx]) = s;
+        *reinterpret_cast<float4*>(red[1][ty * qs + tx]) = ss;
+    }
     __syncthreads();
-    if (ty == 0 && tx < qs) {
+    if (ty == 0) {
         int C = 4 * C4;
         double* o = part + (((size_t)b * nchunks + chunk) * C + 4 * q) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double a0 = 0, a1 = 0;
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                a0 += (double)red[0][l][tx][j];
-                a1 += (double)red[1][l][tx][j];
+            for (int l = 0; l < rl; ++l) {   // fixed order: deterministic
+                a0 += (double)red[0][l * qs + tx][j];
+                a1 += (double)red[1][l * qs + tx][j];
             }
             o[2 * j] = a0;
             o[2 * j + 1] = a1;
@@ -183,15 +195,24 @@ __global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restric
                                                           float* __restrict__ a_out, float* __restrict__ s_out,
                                                           float* __restrict__ mean_out,
                                                           float* __restrict__ pooled_out, int B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    int b = i / C, c = i % C;
+    // 16 lanes per (b, c): lane l adds chunks l, l+16, ... then the 16 partial sums are combined by a fixed butterfly
+    // (bit-reproducible); a single thread walking 128 chunk partials was latency-bound (12 us per launch)
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gi >> 4, l = gi & 15;
+    const bool valid = i < B * C;
+    const int b = valid ? i / C : 0, c = valid ? i % C : 0;
     double s = 0, ss = 0;
-    for (int k = 0; k < nchunks; ++k) {
+    for (int k = l; k < nchunks; k += 16) {
         const double* p = part + (((size_t)b * nchunks + k) * C + c) * 2;
         s += p[0];
         ss += p[1];
     }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    if (!valid || l != 0) return;
     double K = (double)x[(size_t)b * n * ldx + c];
     double md = s / n;
     double mean = K + md;
@@ -235,7 +256,7 @@ extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, fl
     hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
                        nchunks);
     UWIR_LAUNCH_CHECK("ln_partial");
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, C,
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(B * C * 16, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, C,
                        (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out,
                        pooled_out, B);
     UWIR_LAUNCH_CHECK("ln_finalize");
