@@ -478,6 +478,25 @@ def test_conv_gemm_resblock_epilogue_and_upsample(ops, prec):
     assert rel(from_rows(up, b, 2 * h, 2 * w), refu) < tol
 
 
+@pytest.mark.parametrize("adt", ["fp32", "bf16"])
+@pytest.mark.parametrize("n", [256, 192, 64])
+def test_conv3x3_halo_tiles(ops, adt, n):
+    """bf16 3x3 convs run over LDS-staged halo tiles: many tiles (the 128-wide channel tile needs >= 512 blocks), ragged
+    image edges against the 8 x 16 pixel tile, a partial channel tile, fp32 and bf16 activations, residual epilogue."""
+    g = torch.Generator().manual_seed(41)
+    b, c, h, w = 2, 32, 125, 130
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(n, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    bias, res = torch.randn(n, generator=g), torch.randn(b, n, h, w, generator=g)
+    xin = to_rows(x).to(_wdt(adt))
+    xe = xin.float().cpu().reshape(b, h, w, c).permute(0, 3, 1, 2).double()
+    out = torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(xin, wt.permute(0, 2, 3, 1).reshape(n, -1).bfloat16().cuda().contiguous(), out, B=b, H=h, W=w, C_=c, N=n,
+                  KH=3, KW=3, pad=1, bias=bias.cuda(), res=to_rows(res))
+    ref = F.conv2d(xe, wt.bfloat16().double(), bias.double(), padding=1) + res.double()
+    assert rel(from_rows(out, b, h, w), ref) < 1e-2
+
+
 def test_groupnorm_affine(ops):
     g = torch.Generator().manual_seed(16)
     for (b, c, h, w) in ((2, 128, 4, 4), (1, 256, 32, 32), (3, 64, 5, 7)):
