@@ -192,6 +192,143 @@ __global__ void __launch_bounds__(256) la_apply_kernel(const T* __restrict__ q, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 form of passes (2) and (3) on the matrix cores.  The VALU kernels above spend 1024 FMAs per (row, head) in each
+// pass (2.1 GFMA per pass at B = 8, 256^2: 3x the time the HBM traffic needs).  Both contractions are 32-wide GEMMs:
+//   ctx:   A = E^T (d x rows), B = V (rows x e): the contracted index is the ROW, i.e. the slow index of the row-major
+//          inputs, so the 64-row tiles are transposed on their way into LDS ([d][row] / [e][row]) and every wave feeds
+//          16 rows per v_mfma_f32_32x32x16_bf16; the row sums S[d] ride along as A x ones.
+//   apply: A = softmax_d(q) (rows x d) is row-major as stored (16-byte fragments straight from global), B = ctx from an
+//          LDS copy kept transposed; the softmax normalisation is folded into A.
+// E, V, softmax(q) and ctx enter the MFMAs rounded to bf16 (fp32 accumulation); the fp32 path keeps the VALU kernels.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) la_ctx_mfma_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                          int ld, int n, int heads, int nchunks,
+                                                          const float* __restrict__ pmax, float* __restrict__ part) {
+    constexpr int D = LA_D, TR = 64, STR = TR + 8;
+    const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int HD = heads * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 31, kg = lane >> 5;
+    __shared__ __attribute__((aligned(16))) bf16_t sEt[D * STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sVt[D * STR];
+    __shared__ float sMax[D];
+    __shared__ float red[4][D][D + 1];
+    __shared__ float redS[4][D];
+    if (tid < D) {
+        float m = -INFINITY;
+        for (int c = 0; c < nchunks; ++c) m = fmaxf(m, pmax[((size_t)b * nchunks + c) * HD + head * D + tid]);
+        sMax[tid] = m;
+    }
+    __syncthreads();
+    f32x16 acc, accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accS[r] = 0.f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
+    const int r0 = chunk * LA_CHUNK, r1 = min(n, r0 + LA_CHUNK);
+    const int rr = tid >> 2, c8 = (tid & 3) * 8;
+    for (int t0 = r0; t0 < r1; t0 += TR) {
+        {   // stage 64 rows: E = exp(k - max_d) and V, transposed to [column][row]
+            const int r = t0 + rr;
+            const bool ok = r < r1;
+            const size_t off = ((size_t)b * n + (ok ? r : r0)) * ld + head * D + c8;
+            const bf16x8 kk = *reinterpret_cast<const bf16x8*>(k + off);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(v + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float e = ok ? __builtin_amdgcn_exp2f(((float)kk[j] - sMax[c8 + j]) * 1.4426950408889634f) : 0.f;
+                sEt[(c8 + j) * STR + rr] = (bf16_t)e;
+                sVt[(c8 + j) * STR + rr] = ok ? vv[j] : (bf16_t)0.f;
+            }
+        }
+        __syncthreads();
+        {   // wave w contracts rows 16w .. 16w+15 of the tile
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sEt[lq * STR + 16 * wave + 8 * kg]);
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&sVt[lq * STR + 16 * wave + 8 * kg]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accS, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // accumulator: column e = lq, rows d = (r&3) + 8(r>>2) + 4kg
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        red[wave][d][lq] = acc[r];
+        if (lq == 0) redS[wave][d] = accS[r];
+    }
+    __syncthreads();
+    const int d = tid >> 3, eq = tid & 7;
+    float* o = part + (((size_t)b * heads + head) * nchunks + chunk) * (D * D + D);
+    float4 t;
+    t.x = red[0][d][4 * eq] + red[1][d][4 * eq] + red[2][d][4 * eq] + red[3][d][4 * eq];
+    t.y = red[0][d][4 * eq + 1] + red[1][d][4 * eq + 1] + red[2][d][4 * eq + 1] + red[3][d][4 * eq + 1];
+    t.z = red[0][d][4 * eq + 2] + red[1][d][4 * eq + 2] + red[2][d][4 * eq + 2] + red[3][d][4 * eq + 2];
+    t.w = red[0][d][4 * eq + 3] + red[1][d][4 * eq + 3] + red[2][d][4 * eq + 3] + red[3][d][4 * eq + 3];
+    store4(o + d * D + 4 * eq, t);
+    if (eq == 0) o[D * D + d] = redS[0][d] + redS[1][d] + redS[2][d] + redS[3][d];
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(256) la_apply_mfma_kernel(const bf16_t* __restrict__ q, int ld, int n, int heads,
+                                                            const float* __restrict__ ctx, TO* __restrict__ out, int ldo) {
+    constexpr int D = LA_D, CS = D + 8;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 31, kg = lane >> 5;
+    __shared__ __attribute__((aligned(16))) bf16_t sCt[D * CS];   // ctx transposed: [e][d]
+    for (int i = tid; i < D * D; i += 256) sCt[(i % D) * CS + i / D] = (bf16_t)ctx[((size_t)b * heads + head) * D * D + i];
+    __syncthreads();
+    bf16x8 cb[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) cb[st] = *reinterpret_cast<const bf16x8*>(&sCt[lq * CS + 16 * st + 8 * kg]);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int base = blockIdx.x * 256 + wave * 64 + g * 32;
+        if (base >= n) break;   // wave-uniform
+        const int r = min(base + lq, n - 1);
+        const bf16_t* qr = q + ((size_t)b * n + r) * ld + head * D + 8 * kg;
+        float f[16];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(qr + 16 * st);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[8 * st + j] = (float)t[j];
+        }
+        float m = f[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) m = fmaxf(m, f[j]);
+        {   // the other 16 values of the row sit in lane ^ 32
+            unsigned u = __float_as_uint(m);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { f[j] = __builtin_amdgcn_exp2f((f[j] - m) * 1.4426950408889634f); ssum += f[j]; }
+        {
+            unsigned u = __float_as_uint(ssum);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            ssum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float inv = 1.f / ssum;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = (bf16_t)(f[8 * st + j] * inv);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, cb[st], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // accumulator: column e = lq, rows = (i&3) + 8(i>>2) + 4kg of this 32-row group
+            const int row = base + (i & 3) + 8 * (i >> 2) + 4 * kg;
+            if (row < n) out[((size_t)b * n + row) * ldo + head * D + lq] = (TO)acc[i];
+        }
+    }
+}
+
 extern "C" size_t uwir_linattn_workspace_bytes(int B, int n, int heads) {
     size_t nchunks = ceil_div(n, LA_CHUNK);
     size_t HD = (size_t)heads * LA_D;
@@ -212,7 +349,13 @@ static int linattn_launch(const void* qkv, int ld, int B, int n, int heads, void
     float* ctx = part + (size_t)B * heads * nchunks * (D * D + D);
     hipLaunchKernelGGL(la_kmax_kernel<T>, dim3(nchunks, B), dim3(256), 0, s, k, ld, n, HD, nchunks, pmax);
     UWIR_LAUNCH_CHECK("linattn(kmax)");
-    hipLaunchKernelGGL(la_ctx_kernel<T>, dim3(nchunks, heads, B), dim3(256), 0, s, k, v, ld, n, heads, nchunks, pmax, part);
+    constexpr bool BF = sizeof(T) == 2;
+    const bool mfma = BF && ld % 8 == 0;   // 16-byte fragments
+    if constexpr (BF) {
+        if (mfma) hipLaunchKernelGGL(la_ctx_mfma_kernel, dim3(nchunks, heads, B), dim3(256), 0, s, (const bf16_t*)k,
+                                     (const bf16_t*)v, ld, n, heads, nchunks, pmax, part);
+    }
+    if (!mfma) hipLaunchKernelGGL(la_ctx_kernel<T>, dim3(nchunks, heads, B), dim3(256), 0, s, k, v, ld, n, heads, nchunks, pmax, part);
     UWIR_LAUNCH_CHECK("linattn(ctx)");
     const int total = B * heads * D * D;
     // q * D^-0.5 and v / n (module_util.py:176-177) are folded into the context
@@ -220,6 +363,18 @@ static int linattn_launch(const void* qkv, int ld, int B, int n, int heads, void
     hipLaunchKernelGGL(la_fin_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, part, nchunks, inv_n_scale, ctx, total);
     UWIR_LAUNCH_CHECK("linattn(fin)");
     dim3 grid(ceil_div(n, 256), heads, B);
+    if constexpr (BF) {
+        if (mfma) {
+            if (out_dtype == UWIR_F32)
+                hipLaunchKernelGGL(la_apply_mfma_kernel<float>, grid, dim3(256), 0, s, (const bf16_t*)q, ld, n, heads, ctx,
+                                   (float*)out, ldo);
+            else
+                hipLaunchKernelGGL(la_apply_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)q, ld, n, heads, ctx,
+                                   (bf16_t*)out, ldo);
+            UWIR_LAUNCH_CHECK("linattn(apply, mfma)");
+            return UWIR_OK;
+        }
+    }
     if (out_dtype == UWIR_F32)
         hipLaunchKernelGGL((la_apply_kernel<T, float>), grid, dim3(256), 0, s, q, ld, n, heads, ctx, (float*)out, ldo,
                            (size_t)B * n);
