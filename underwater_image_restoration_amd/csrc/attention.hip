@@ -509,6 +509,8 @@ template <int HD, int NV> struct PackCfg {
 
 __host__ __device__ static inline size_t pk_align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+#define PK_TILES 4   // 256-key tiles per block of the pack pre-pass (the next tile's loads fly during the current gather)
+
 template <int HD, int NV>
 __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ v1,
                                                         int ldv1, const bf16_t* __restrict__ v2, int ldv2, int n, int npad,
@@ -517,61 +519,76 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
     using P = PackCfg<HD, NV>;
     constexpr int DV = P::DV, ROWS = P::ROWS, SV = DV + 8;  // LDS row stride (elements): rows stay 16-byte aligned
     constexpr int PPK = HD / 8;                             // 16-byte pieces per key row
+    constexpr int NIT = PK_KEYS * PPK / 256;
     __shared__ __attribute__((aligned(16))) bf16_t sV[PK_KEYS * SV];
     const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int bh = b * heads + head;
-    const int k0 = blockIdx.x * PK_KEYS;
     float m = 0.f;
-    // ---- phase 1: 16-byte pieces, adjacent lanes = adjacent pieces of one key row (K straight to its packed place,
-    //      V rows into LDS for the transposition)
+    bf16x8 kv[NIT], vv[NIT][NV];
+    // 16-byte pieces, adjacent lanes = adjacent pieces of one key row
+    auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < PK_KEYS * PPK / 256; ++it) {
-        const int idx = tid + 256 * it;
-        const int kl = idx / PPK, piece = idx % PPK, key = k0 + kl;
-        bf16x8 kv, vv[NV];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int key = k0 + idx / PPK, piece = idx % PPK;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) kv[e] = (bf16_t)0.f;
+            for (int e = 0; e < 8; ++e) kv[it][e] = (bf16_t)0.f;
 #pragma unroll
-        for (int t = 0; t < NV; ++t) vv[t] = kv;
-        if (key < n) {
-            const size_t r = (size_t)b * n + key;
-            kv = *reinterpret_cast<const bf16x8*>(k + r * ldk + (size_t)head * HD + piece * 8);
-            vv[0] = *reinterpret_cast<const bf16x8*>(v1 + r * ldv1 + (size_t)head * HD + piece * 8);
-            if constexpr (NV > 1) vv[1] = *reinterpret_cast<const bf16x8*>(v2 + r * ldv2 + (size_t)head * HD + piece * 8);
+            for (int t = 0; t < NV; ++t) vv[it][t] = kv[it];
+            if (key < n) {
+                const size_t r = (size_t)b * n + key;
+                kv[it] = *reinterpret_cast<const bf16x8*>(k + r * ldk + (size_t)head * HD + piece * 8);
+                vv[it][0] = *reinterpret_cast<const bf16x8*>(v1 + r * ldv1 + (size_t)head * HD + piece * 8);
+                if constexpr (NV > 1) vv[it][1] = *reinterpret_cast<const bf16x8*>(v2 + r * ldv2 + (size_t)head * HD + piece * 8);
+            }
         }
-        float s = 0.f;
+    };
+    const int kb0 = blockIdx.x * (PK_KEYS * PK_TILES);
+    load_tile(kb0);
+    for (int t = 0; t < PK_TILES; ++t) {
+        const int k0 = kb0 + t * PK_KEYS;
+        if (k0 >= npad) break;
+        // ---- phase 1: K straight to its packed place, V rows into LDS for the transposition
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float f = (float)kv[e]; s = fmaf(f, f, s); }
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int kl = idx / PPK, piece = idx % PPK, key = k0 + kl;
+            float s = 0.f;
 #pragma unroll
-        for (int off = 1; off < PPK; off <<= 1) s += __shfl_xor(s, off);   // the PPK lanes of one key
-        m = fmaxf(m, s);
-        if (key < npad) *reinterpret_cast<bf16x8*>(Kp + ((size_t)bh * npad + key) * HD + piece * 8) = kv;
+            for (int e = 0; e < 8; ++e) { float f = (float)kv[it][e]; s = fmaf(f, f, s); }
 #pragma unroll
-        for (int t = 0; t < NV; ++t) *reinterpret_cast<bf16x8*>(&sV[kl * SV + t * HD + piece * 8]) = vv[t];
+            for (int off = 1; off < PPK; off <<= 1) s += __shfl_xor(s, off);   // the PPK lanes of one key
+            m = fmaxf(m, s);
+            if (key < npad) *reinterpret_cast<bf16x8*>(Kp + ((size_t)bh * npad + key) * HD + piece * 8) = kv[it];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) *reinterpret_cast<bf16x8*>(&sV[kl * SV + u * HD + piece * 8]) = vv[it][u];
+        }
+        __syncthreads();
+        if (t + 1 < PK_TILES && k0 + PK_KEYS < npad) load_tile(k0 + PK_KEYS);
+        // ---- phase 2: one item = one V^T row of one 16-key group: 16 keys gathered in accumulator order, one 32-byte
+        //      store; adjacent lanes = adjacent rows, so a key group's ROWS x 32 bytes leave as one contiguous run
+        for (int item = tid; item < (PK_KEYS / 16) * ROWS; item += 256) {
+            const int kg = item / ROWS, row = item - kg * ROWS;
+            const int kbase = k0 + kg * 16;
+            if (kbase >= npad) continue;
+            bf16x8 o[2];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                const int kk = 8 * ((pos >> 2) & 1) + 4 * (pos >> 3) + (pos & 3);  // bits 2 and 3 swapped (an involution)
+                bf16_t val;
+                if (row < DV) val = sV[(kg * 16 + kk) * SV + row];
+                else val = (bf16_t)((kbase + kk) < n ? 1.f : 0.f);
+                o[pos >> 3][pos & 7] = val;
+            }
+            bf16_t* dst = Vtp + (((size_t)bh * (npad / 16) + kbase / 16) * ROWS + row) * 16;
+            *reinterpret_cast<bf16x8*>(dst) = o[0];
+            *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if ((tid & 63) == 0 && m > 0.f) atomicMax(kmax2 + bh, __float_as_uint(m));
-    __syncthreads();
-    // ---- phase 2: one item = one V^T row of one 16-key group: 16 keys gathered in accumulator order, one 32-byte
-    //      store; adjacent lanes = adjacent rows, so a key group's ROWS x 32 bytes leave as one contiguous run
-    for (int item = tid; item < (PK_KEYS / 16) * ROWS; item += 256) {
-        const int kg = item / ROWS, row = item - kg * ROWS;
-        const int kbase = k0 + kg * 16;
-        if (kbase >= npad) continue;
-        bf16x8 o[2];
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const int kk = 8 * ((pos >> 2) & 1) + 4 * (pos >> 3) + (pos & 3);  // bits 2 and 3 swapped (an involution)
-            bf16_t val;
-            if (row < DV) val = sV[(kg * 16 + kk) * SV + row];
-            else val = (bf16_t)((kbase + kk) < n ? 1.f : 0.f);
-            o[pos >> 3][pos & 7] = val;
-        }
-        bf16_t* dst = Vtp + (((size_t)bh * (npad / 16) + kbase / 16) * ROWS + row) * 16;
-        *reinterpret_cast<bf16x8*>(dst) = o[0];
-        *reinterpret_cast<bf16x8*>(dst + 8) = o[1];
-    }
 }
 
 template <int HD, int NV, int QG, int PF>
@@ -807,7 +824,7 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
     bf16_t* Vtp = (bf16_t*)(base + pk_align256(bh * npad * HD * 2));
     if ((size_t)npad * HD * 2 >= 0x7fffffffULL || (size_t)(npad / 16) * P::ROWS * 32 >= 0x7fffffffULL)
         return uwir_set_error(UWIR_EINVAL, "flash_attn: sequence too long for the packed stream");
-    hipLaunchKernelGGL((attn_pack_kernel<HD, NV>), dim3(ceil_div(npad, PK_KEYS), p.heads, B), dim3(256), 0, stream,
+    hipLaunchKernelGGL((attn_pack_kernel<HD, NV>), dim3(ceil_div(npad, PK_KEYS * PK_TILES), p.heads, B), dim3(256), 0, stream,
                        (const bf16_t*)p.k, p.ldk, (const bf16_t*)p.v[0], p.ldv[0], (const bf16_t*)p.v[1], p.ldv[1], n, npad,
                        p.heads, Kp, Vtp, (unsigned*)workspace);
     UWIR_LAUNCH_CHECK("flash_attn(pack)");
