@@ -271,6 +271,14 @@ size_t uwir_image_metrics_workspace_bytes(int B, int C, int H, int W);
 int uwir_image_metrics(const float* x_nchw, const float* y_nchw, int B, int C, int H, int W, float c1, float c2, float* out,
                        void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
+/* ---- L/utils/img_utils.py:136-163 tensor2img (3-D / 2-D case) and :182-189 calculate_psnr --------------------------
+ * x CHW fp32 -> out HWC uint8 = round_half_even(255 * (clamp(x, lo, hi) - lo) / (hi - lo)), channel order reversed
+ * when reverse_channels (RGB -> BGR, the reference's [2, 1, 0] gather); same fp32 operation order, identical bytes.
+ * uwir_sqdiff_u8: *out = sum_i (a[i] - b[i])^2 over n bytes (exact); PSNR = 20 log10(255 / sqrt(*out / n)). */
+int uwir_tensor2img_u8(const float* x_chw, int C, int H, int W, float lo, float hi, int reverse_channels,
+                       uint8_t* out_hwc, uwir_stream_t stream);
+int uwir_sqdiff_u8(const uint8_t* a, const uint8_t* b, size_t n, unsigned long long* out, uwir_stream_t stream);
+
 /* ---- teacher heads: tokens x prompt embeddings -> masks / statistics -> degradation code z_d ----------------------
  * underwater_ir/teacher/mask_head.py:96-164 (MaskHead.forward), differentiable_crf.py:44-80 (DifferentiableGuidedCRF,
  * mean-field iterations with a normalised Gaussian and an edge mask from the guidance image) and deg_coder.py:31-59

@@ -261,6 +261,40 @@ def metrics_case() -> None:
     print("metrics:", {k: float(v) for k, v in store.items() if k.endswith("ssim_loss")})
 
 
+def imgutil_case() -> None:
+    """tensor2img / calculate_psnr of L/utils/img_utils.py.  The module imports cv2 and torchvision.utils.make_grid at
+    the top for OTHER functions (save_img, the 4-D grid branch); both are absent here, so empty module objects stand in
+    for the import statement only (as SURVEY.md section 8c does for sde_utils.py) -- the two functions used are numpy."""
+    import importlib.util
+    import types
+    for name in ("cv2", "torchvision", "torchvision.utils"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    spec = importlib.util.spec_from_file_location(
+        "ref_img_utils", "/root/reference/legacy/third_party/universal-image-restoration/utils/img_utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(61)
+    a = torch.rand(1, 3, 37, 53, generator=g) * 1.4 - 0.2                 # values outside [0, 1] get clamped
+    ties = (torch.arange(0, 256, dtype=torch.float32) + 0.5) / 255.0     # x * 255 lands on .5: round half to even
+    a[0, 0, 0, :53] = ties[:53]
+    a[0, 1, 1, :53] = ties[100:153]
+    b = (a + 0.03 * torch.randn(a.shape, generator=g))
+    gray = torch.rand(19, 23, generator=g)
+    wide = torch.randn(3, 16, 16, generator=g) * 3
+    store = {"a": a.numpy(), "b": b.numpy(), "gray": gray.numpy(), "wide": wide.numpy()}
+    ia, ib = mod.tensor2img(a.clone()), mod.tensor2img(b.clone())
+    store["a_img"], store["b_img"] = ia, ib
+    store["gray_img"] = mod.tensor2img(gray.clone())
+    store["wide_img"] = mod.tensor2img(wide.clone(), min_max=(-1, 1))
+    store["psnr_ab"] = np.float64(mod.calculate_psnr(ia, ib))
+    store["psnr_aa"] = np.float64(mod.calculate_psnr(ia, ia))
+    np.savez_compressed(os.path.join(HERE, "imgutil.npz"), **store)
+    print("imgutil: psnr", float(store["psnr_ab"]), "shapes", ia.shape, store["gray_img"].shape)
+
+
 def teacher_inputs(name: str):
     """Seeded inputs of the teacher-head cases (shared with the tests through tests/golden/cases.py would need torch
     only; kept here and stored in the .npz because they are tiny)."""
@@ -323,7 +357,7 @@ def teacher_case() -> None:
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics", "teacher"}
+    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics", "teacher", "imgutil"}
     if "dwt" in which:
         dwt_case()
     if "student" in which:
@@ -341,3 +375,5 @@ if __name__ == "__main__":
         metrics_case()
     if "teacher" in which:
         teacher_case()
+    if "imgutil" in which:
+        imgutil_case()

@@ -94,6 +94,8 @@ _SIGS = {
     "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_image_metrics_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "uwir_image_metrics": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, sz, vp]),
+    "uwir_tensor2img_u8": (ci, [vp, ci, ci, ci, cf, cf, ci, vp, vp]),
+    "uwir_sqdiff_u8": (ci, [vp, vp, sz, vp, vp]),
     "uwir_teacher_heads_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_teacher_heads": (ci, [C.POINTER(TeacherArgs), vp]),
     "uwir_guided_crf": (ci, [C.POINTER(TeacherArgs), vp, vp, vp]),

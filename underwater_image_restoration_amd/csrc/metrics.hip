@@ -117,3 +117,64 @@ extern "C" int uwir_image_metrics(const float* x_nchw, const float* y_nchw, int 
     UWIR_LAUNCH_CHECK("image_metrics(finalize)");
     return UWIR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// L/utils/img_utils.py:136-163 tensor2img: clamp to [lo, hi], rescale to [0, 1], x 255, round half to even (numpy
+// .round()), uint8, CHW -> HWC with the channel order reversed (RGB -> BGR).  Same fp32 operation order as the
+// reference, so the bytes are identical.  4 bytes in, 1 byte out per element: the D2H copy of a result shrinks 4x.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tensor2img_kernel(const float* __restrict__ x, int C, int H, int W, float lo,
+                                                         float hi, int reverse, uint8_t* __restrict__ out) {
+    const size_t total = (size_t)C * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);           // output is HWC: i = (y * W + x) * C + c
+        const size_t pix = i / C;
+        const int cs = reverse ? C - 1 - c : c;
+        float v = x[(size_t)cs * H * W + pix];
+        v = fminf(fmaxf(v, lo), hi);
+        v = (v - lo) / (hi - lo);
+        out[i] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
+extern "C" int uwir_tensor2img_u8(const float* x_chw, int C, int H, int W, float lo, float hi, int reverse_channels,
+                                  uint8_t* out_hwc, uwir_stream_t stream) {
+    UWIR_CHECK(x_chw && out_hwc, "tensor2img: null pointer");
+    UWIR_CHECK(C > 0 && H > 0 && W > 0 && hi > lo, "tensor2img: bad shape / range");
+    const size_t total = (size_t)C * H * W;
+    size_t g = ceil_div_sz(total, 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(tensor2img_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x_chw, C, H, W, lo, hi,
+                       reverse_channels, out_hwc);
+    UWIR_LAUNCH_CHECK("tensor2img");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// L/utils/img_utils.py:182-189 calculate_psnr on [0, 255] images: the sum of squared uint8 differences, exact in
+// integers (integer atomics commute: bit-reproducible); the caller forms 20 log10(255 / sqrt(sum / n)).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sqdiff_u8_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                        size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)a[i] - (int)b[i];
+        s += (unsigned)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int uwir_sqdiff_u8(const uint8_t* a, const uint8_t* b, size_t n, unsigned long long* out, uwir_stream_t stream) {
+    UWIR_CHECK(a && b && out && n > 0, "sqdiff_u8: null pointer / empty input");
+    UWIR_CHECK(((uintptr_t)out & 7) == 0, "sqdiff_u8: out must be 8-byte aligned");
+    if (hipMemsetAsync(out, 0, sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+        return uwir_set_error(UWIR_ELAUNCH, "sqdiff_u8: hipMemsetAsync failed");
+    size_t g = ceil_div_sz(n, 256 * 16);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(sqdiff_u8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+    UWIR_LAUNCH_CHECK("sqdiff_u8");
+    return UWIR_OK;
+}
