@@ -186,7 +186,7 @@ def main() -> None:
             fl = 4.0 * args.batch * 12 * float(n0) ** 2 * (args.size and 16)  # 4*B*heads*n^2*hd
             ach = fl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            roof = {"bound": "mfma", "kernel": "attn_stream_kernel<hd16,1V,QG2> (WTB level-0 attention, main launch only: HIP events armed "
+            roof = {"bound": "mfma", "kernel": "attn_stream_kernel<hd16,1V,QG4> (WTB level-0 attention, main launch only: HIP events armed "
                               "through uwir_flash_attn_probe on the launch stream)", "achieved": round(ach, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}

@@ -413,12 +413,15 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             const int buf = t & 1;
             if (t + 1 < ntiles) load_tile((t + 1) * KT);
             const int k0 = t * KT;
-            block(0, buf, k0, GIdx<0>{});
-            if constexpr (QG > 1) block(0, buf, k0, GIdx<QG - 1>{});
-            if (k0 + 32 < n) {
-                block(1, buf, k0, GIdx<0>{});
-                if constexpr (QG > 1) block(1, buf, k0, GIdx<QG - 1>{});
-            }
+            auto all_groups = [&](const int kb) {
+                block(kb, buf, k0, GIdx<0>{});
+                if constexpr (QG > 1) block(kb, buf, k0, GIdx<1>{});
+                if constexpr (QG > 2) block(kb, buf, k0, GIdx<2>{});
+                if constexpr (QG > 3) block(kb, buf, k0, GIdx<3>{});
+                static_assert(QG <= 4, "at most 4 query groups per wave");
+            };
+            all_groups(0);
+            if (k0 + 32 < n) all_groups(1);
             if (t + 1 < ntiles) store_tile(buf ^ 1);
             __syncthreads();
         }
@@ -919,10 +922,12 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
         if (attn_packed_shape(B, n, heads, hd, nv) && workspace_bytes >= attn_packed_bytes(B, n, heads, hd, nv) &&
             ((uintptr_t)workspace & 255) == 0) {
             // the pack pre-pass also produces max|k|^2
-            if (hd == 16) return nv == 1 ? launch_attn_packed<16, 1, 2, 2>(p, B, workspace, s)
-                                         : launch_attn_packed<16, 2, 2, 2>(p, B, workspace, s);
-            return nv == 1 ? launch_attn_packed<32, 1, 2, 2>(p, B, workspace, s)
-                           : launch_attn_packed<32, 2, 1, 2>(p, B, workspace, s);
+            // (QG, PF) per shape measured on MI355X (tools/bench_attn.py): hd16 1V 4.84 -> 4.72 ms with 4 query groups,
+            // hd16 2V 2.29 -> 2.24 and hd32 1V 0.54 -> 0.53 with one block of prefetch, hd32 2V 0.31 -> 0.26 with (2, 1)
+            if (hd == 16) return nv == 1 ? launch_attn_packed<16, 1, 4, 2>(p, B, workspace, s)
+                                         : launch_attn_packed<16, 2, 2, 1>(p, B, workspace, s);
+            return nv == 1 ? launch_attn_packed<32, 1, 2, 1>(p, B, workspace, s)
+                           : launch_attn_packed<32, 2, 2, 1>(p, B, workspace, s);
         }
         hipLaunchKernelGGL(attn_kmax_kernel, dim3(ceil_div(n, KMAX_ROWS), heads, B), dim3(256), 0, s, (const bf16_t*)k, ldk,
                            n, heads, hd, (unsigned*)workspace);
