@@ -68,16 +68,24 @@ def main() -> None:
     ap.add_argument("--sde-steps", type=int, default=100)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the ranks rendezvous over gloo "
+                         "(checks the barrier / max-over-ranks / rank-0 reporting logic; the number is not a result)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from underwater_image_restoration_amd import ops
     from underwater_image_restoration_amd.student import NAFNetWFIGate
@@ -166,7 +174,7 @@ def main() -> None:
     timings = ops.collect_event_timings()
     ops.event_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,7 +206,7 @@ def main() -> None:
             "metric": "restored megapixels/sec (whole node)", "value": round(mp / elapsed, 4),
             "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if args.rehearse else ""),
             "config": {"workload": f"BASELINE configs[1]: DA-CLIP ViT-B/32 encode_image(control=True) -> z_d (512) -> student "
                                    f"NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
                                    f"{args.precision} MFMA compute, masks (10,7,7)",
