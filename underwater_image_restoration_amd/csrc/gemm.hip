@@ -69,65 +69,142 @@ __device__ __forceinline__ void linear_rows(int (&mrow)[TM], int (&mcnt)[TM], in
     }
 }
 
+// bias, per-sample scale / bias, activation, column scale, affine residual, gate blend for the lane's 16 channels of
+// output row `out_row` (image b).  Feature-outer, channel-inner: every `if (g.x)` is one block-uniform branch around a
+// group of INDEPENDENT loads that fly together, and the bias is loaded once per lane (epi_cols), not per row group.  (Channel-outer with the feature tests inside, every (i, j) piece exposed the
+// latency of each of its loads in turn -- 16 dependent L2 round trips per wave for a plain bias: with them a block's
+// epilogue took as long as its whole K loop at K = 192.)  Per element the operations and their order are unchanged.
+template <int TN>
+struct EpiCols {
+    f32x4 bias[TN];
+};
+template <int TN>
+__device__ __forceinline__ void epi_cols(const uwir_gemm_args& g, int n_base, int fq, EpiCols<TN>& c) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + fq * 16 + j * 4;
+        const bool in = n < g.N;
+        c.bias[j] = (g.bias && in) ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+// EPI (compile-time epilogue class, chosen by epi_class on the host): EPI_FULL everything; EPI_LEAN no residual / blend /
+// per-sample scale / scatter, and the bias is ALREADY in the accumulators (the kernel initialised them with it: its load
+// overlaps the first K tile instead of standing between the last MFMA and the stores); EPI_RES = EPI_LEAN + a plain
+// fp32 residual.  The lean classes keep the plain 1x1 GEMMs at 4 resident blocks per CU (<= 128 VGPRs).
+#define EPI_FULL 0
+#define EPI_LEAN 1
+#define EPI_RES 2
+template <int TN, int EPI>
+__device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 (&acc)[TN], const EpiCols<TN>& c, size_t out_row,
+                                           int b, int n_base, int fq, f32x4 (&v)[TN]) {
+    const int N = g.N;
+    const int bld = g.batch_ld ? g.batch_ld : N;
+    const int nq = n_base + fq * 16;   // + j * 4
+    auto ld = [&](const float* ptr, int j) {
+        return nq + j * 4 < N ? *reinterpret_cast<const f32x4*>(ptr + nq + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) v[j] = acc[j];
+    if (EPI == EPI_FULL && g.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) v[j] += c.bias[j];
+    }
+    if (EPI == EPI_FULL && g.batch_scale) {
+        f32x4 t[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) t[j] = ld(g.batch_scale + (size_t)b * bld, j);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) v[j] *= t[j];
+    }
+    if (g.batch_bias) {
+        f32x4 t[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) t[j] = ld(g.batch_bias + (size_t)b * bld, j);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) v[j] += t[j];
+    }
+    if (g.act != UWIR_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = act_apply(v[j][e], g.act);
+    }
+    if (g.col_scale) {
+        f32x4 t[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) t[j] = ld(g.col_scale, j);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) v[j] *= t[j];
+    }
+    if (EPI != EPI_LEAN && g.res) {
+        f32x4 r[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) r[j] = ld(g.res + out_row * g.ldr, j);
+        if (EPI == EPI_FULL && g.res_scale) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 s4 = ld(g.res_scale + (size_t)b * N, j), h4 = ld(g.res_shift + (size_t)b * N, j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[j][e] = fmaf(r[j][e], s4[e], h4[e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) v[j] += r[j];
+    }
+    if (EPI == EPI_FULL && g.blend_out) {
+        f32x4 t[TN], f[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            t[j] = ld(g.blend_t + out_row * g.ld_blend_in, j);
+            f[j] = ld(g.blend_f + out_row * g.ld_blend_in, j);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (nq + j * 4 >= N) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[j][e] * t[j][e] + (1.f - v[j][e]) * f[j][e];
+            *reinterpret_cast<f32x4*>(g.blend_out + out_row * g.ld_blend_out + nq + j * 4) = o;
+        }
+    }
+}
+
+static int epi_class(const uwir_gemm_args& g) {
+    if (g.blend_out || g.batch_scale || g.store_mode != 0 || !g.out || g.res_scale) return EPI_FULL;
+    return g.res ? EPI_RES : EPI_LEAN;
+}
+// accumulator start values of a lean-class kernel: the bias of the lane's channels (see gemm_epilogue for the mapping)
 template <int TM, int TN>
+__device__ __forceinline__ void acc_init_bias(const uwir_gemm_args& g, f32x4 (&acc)[TM][TN], int n_base, int fq) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + fq * 16 + j * 4;
+        const f32x4 b4 = (g.bias && n < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = b4;
+    }
+}
+template <int TM, int TN, int EPI = EPI_FULL>
 __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], const int (&mrow)[TM],
                                               const int (&mcnt)[TM], int n_base, int fr, int fq) {
     static_assert(TN == 4, "the channel permutation assumes 4 MFMA tiles per 64-channel wave block");
     const int N = g.N;
     const int OHW = g.OH * g.OW;
     const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
-    const int bld = g.batch_ld ? g.batch_ld : N;
+    EpiCols<TN> cols;
+    if (EPI == EPI_FULL) epi_cols<TN>(g, n_base, fq, cols);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        f32x4 vv[TN];
+        {
+            const int m = fr < mcnt[i] ? mrow[i] + fr : 0;
+            if (fr < mcnt[i]) epi_values<TN, EPI>(g, acc[i], cols, (size_t)m, m / OHW, n_base, fq, vv);
+        }
         if (fr >= mcnt[i]) continue;
         int m = mrow[i] + fr;
         int b = m / OHW;
         size_t out_row = (size_t)m;
         int rem = m - b * OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
-        float vv[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = n_base + fq * 16 + j * 4;
-            float* v = vv[j];
-            v[0] = acc[i][j][0]; v[1] = acc[i][j][1]; v[2] = acc[i][j][2]; v[3] = acc[i][j][3];
-            if (n >= N) continue;
-            if (g.bias) { float4 t = load4(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-            if (g.batch_scale) {
-                float4 t = load4(g.batch_scale + (size_t)b * bld + n);
-                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
-            }
-            if (g.batch_bias) {
-                float4 t = load4(g.batch_bias + (size_t)b * bld + n);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (g.act != UWIR_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], g.act);
-            }
-            if (g.col_scale) {
-                float4 t = load4(g.col_scale + n);
-                v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w;
-            }
-            if (g.res) {
-                float4 r = load4(g.res + out_row * g.ldr + n);
-                if (g.res_scale) {
-                    float4 s4 = load4(g.res_scale + (size_t)b * N + n), h4 = load4(g.res_shift + (size_t)b * N + n);
-                    r.x = fmaf(r.x, s4.x, h4.x); r.y = fmaf(r.y, s4.y, h4.y);
-                    r.z = fmaf(r.z, s4.z, h4.z); r.w = fmaf(r.w, s4.w, h4.w);
-                }
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            }
-            if (g.blend_out) {
-                float4 t = load4(g.blend_t + out_row * g.ld_blend_in + n);
-                float4 f = load4(g.blend_f + out_row * g.ld_blend_in + n);
-                float4 o;
-                o.x = v[0] * t.x + (1.f - v[0]) * f.x;
-                o.y = v[1] * t.y + (1.f - v[1]) * f.y;
-                o.z = v[2] * t.z + (1.f - v[2]) * f.z;
-                o.w = v[3] * t.w + (1.f - v[3]) * f.w;
-                store4(g.blend_out + out_row * g.ld_blend_out + n, o);
-            }
-        }
         if (!g.out) continue;
         // bf16 rows, plain layout: two 16-byte stores cover the lane's 16 channels (when 8-channel groups are whole
         // and the row base is 16-byte aligned); everything else goes out as 4-channel pieces
@@ -150,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
                 int nj = n_base + fq * 16 + j * 4;
                 if (nj >= N) continue;
                 size_t off;
-                if (g.store_mode == 1) {
+                if (EPI == EPI_FULL && g.store_mode == 1) {
                     int qd = nj / Cout4, co = nj - qd * Cout4;
                     int dy = qd >> 1, dx = qd & 1;
                     off = (((size_t)b * 2 * g.OH + 2 * oy + dy) * (2 * g.OW) + 2 * ox + dx) * g.ldo + co;
@@ -396,7 +473,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 // NBUF = 2: tile t+1 streams in while tile t computes (64 KiB LDS, 2 blocks / CU).
 // NBUF = 1: load -> compute per tile (32 KiB LDS, 4 blocks / CU): twice the resident blocks hide more latency than
 // the intra-block overlap does (see launch_gemm) -- this is the variant in use.
-template <int NBUF>
+template <int NBUF, int EPI = EPI_FULL>
 __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     constexpr int BM = 128, BN = 128, BK = 64, TM = 4, TN = 4;
     constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -452,6 +529,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     const int fr = lane & 15, fq = lane >> 4;
+    if (EPI != EPI_FULL) acc_init_bias<TM, TN>(g, acc, n0 + wn0, fq);
     // fragment byte offsets inside a tile: row*128 + ((chunk ^ (row&7)) * 16); row&7 == fr&7 for every i
     int a_off[TM], b_off[TN];
 #pragma unroll
@@ -507,7 +585,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
     }
     int mrow[TM], mcnt[TM];
     linear_rows<TM>(mrow, mcnt, m0 + wm0, M);
-    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
+    gemm_epilogue<TM, TN, EPI>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
 }
 
 // second launch of a split-K GEMM: one block per (output tile, 16-row MFMA group i), same thread <-> element mapping as
@@ -786,7 +864,7 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
         // fewer tiles than CUs: per-tile latency is what matters.  Double-buffered staging (57 -> 44 us at M800 N768
         // K3072) and, when the caller lent a workspace, split-K (see splitk_dump)
         p.splitk = splitk_factor(p.M, p.a.N, p.K, p.a.workspace, p.a.workspace_bytes);
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<2>, dim3(p.nblocks * p.splitk), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<2, EPI_FULL>), dim3(p.nblocks * p.splitk), dim3(256), 0, stream, p);
         if (p.splitk > 1) hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3(p.nblocks * 4), dim3(256), 0, stream, p);
         UWIR_LAUNCH_CHECK("conv_gemm(glds, few tiles)");
         return UWIR_OK;
@@ -795,7 +873,11 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
         // measured on MI355X (tools/bench_gemm.py): the single-buffered form wins at every K of this path, e.g.
         // M262144 N384: K192 0.155 -> 0.124 ms, K768 0.303 -> 0.256; M262144 N576 K1728 0.796 -> 0.689;
         // M16384 N2304 K6912 0.641 -> 0.609.  Four resident blocks per CU hide more than intra-block overlap.
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<1>, dim3(p.nblocks), dim3(256), 0, stream, p);
+        switch (epi_class(p.a)) {
+            case EPI_LEAN: hipLaunchKernelGGL((gemm_bf16_glds_kernel<1, EPI_LEAN>), dim3(p.nblocks), dim3(256), 0, stream, p); break;
+            case EPI_RES: hipLaunchKernelGGL((gemm_bf16_glds_kernel<1, EPI_RES>), dim3(p.nblocks), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_bf16_glds_kernel<1, EPI_FULL>), dim3(p.nblocks), dim3(256), 0, stream, p);
+        }
         UWIR_LAUNCH_CHECK("conv_gemm(glds)");
         return UWIR_OK;
     }
