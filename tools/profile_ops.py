@@ -37,7 +37,10 @@ def gemm_tag(A, Wt, out, **k):
     K = Wt.shape[1]
     N = k["N"]
     extra = ("a=" + str(A.dtype).split(".")[-1][:4] + ("+aff" if k.get("a_scale") is not None else "")
-             + f" k{k.get('KH', 1)}" + (" o=" + str(out.dtype).split(".")[-1][:4] if out is not None else ""))
+             + f" k{k.get('KH', 1)}" + (" o=" + str(out.dtype).split(".")[-1][:4] if out is not None else "")
+             + "".join(" " + nm for nm in ("bias", "batch_bias", "batch_scale", "res", "res_scale", "col_scale", "blend_out")
+                       if k.get(nm) is not None)
+             + (f" act{k['act']}" if k.get("act") else "") + (" d2s" if k.get("store_mode") else ""))
     return (f"M{M} N{N} K{K} {extra}", 2.0 * M * N * K, 0)
 
 
@@ -111,7 +114,7 @@ def main():
     print(f"total {total:.2f} ms over {len(EVENTS)} launches ({args.workload} {args.precision} B{args.batch} {args.size}^2)")
     for (name, tag), (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
         rate = f"{fl * cnt / ms / 1e9:8.0f} TF/s" if fl else (f"{by * cnt / ms / 1e6:8.0f} GB/s*" if by else "")
-        print(f"{ms:8.3f} ms {100 * ms / total:5.1f}%  x{cnt:<3d} {ms / cnt:7.3f}  {name:16s} {tag:60s} {rate}")
+        print(f"{ms:8.3f} ms {100 * ms / total:5.1f}%  x{cnt:<3d} {ms / cnt:7.3f}  {name:16s} {tag:84s} {rate}")
 
 
 if __name__ == "__main__":

@@ -159,24 +159,43 @@ __global__ void __launch_bounds__(512) dwconv_ms32_kernel(const TIN* __restrict_
     const int c0 = blockIdx.x * (4 * D2_Q);
     const int ty0 = (blockIdx.y / tiles_x) * D2_T, tx0 = (blockIdx.y % tiles_x) * D2_T;
 
-    // ---- stage the halo tile: item = (pixel, quad), the quads of a pixel on adjacent lanes (64 contiguous bytes of bf16)
-    for (int i = tid; i < D2_L * D2_L * D2_Q; i += 512) {
-        const int q = i % D2_Q, pix = i / D2_Q;
-        const int lx = pix % D2_L, ly = pix / D2_L;
-        const int iy = ty0 + ly - DW_HALO, ix = tx0 + lx - DW_HALO;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            v = load4(x + (((size_t)b * H + iy) * W + ix) * ldx + c0 + 4 * q);
-            if (in_scale) {
-                const float4 sc = load4(in_scale + (size_t)b * C + c0 + 4 * q);
-                const float4 sh = load4(in_shift + (size_t)b * C + c0 + 4 * q);
+    // ---- stage the halo tile: item = (pixel, quad), the quads of a pixel on adjacent lanes (64 contiguous bytes of bf16).
+    // All of a thread's loads are issued before the first LDS store (a rolled load -> store loop exposes one HBM
+    // round trip per item: 8 in a row per block, which made this kernel latency-bound at 4x its FMA time); the quad
+    // index of an item is tid % 8 for every item, so the normalise-on-load affine is loaded once.
+    {
+        constexpr int NITEM = D2_L * D2_L * D2_Q, NIT = (NITEM + 511) / 512;
+        const int q = tid % D2_Q;
+        float4 raw[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + 512 * it) / D2_Q;
+            const int lx = pix % D2_L, ly = pix / D2_L;
+            const int iy = ty0 + ly - DW_HALO, ix = tx0 + lx - DW_HALO;
+            const bool ok = pix < D2_L * D2_L && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            raw[it] = make_float4(0, 0, 0, 0);
+            if (ok) raw[it] = load4(x + (((size_t)b * H + iy) * W + ix) * ldx + c0 + 4 * q);
+        }
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (in_scale) {
+            sc = load4(in_scale + (size_t)b * C + c0 + 4 * q);
+            sh = load4(in_shift + (size_t)b * C + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + 512 * it) / D2_Q;
+            if (pix >= D2_L * D2_L) continue;
+            const int lx = pix % D2_L, ly = pix / D2_L;
+            const int iy = ty0 + ly - DW_HALO, ix = tx0 + lx - DW_HALO;
+            float4 v = raw[it];
+            if (in_scale && iy >= 0 && iy < H && ix >= 0 && ix < W) {   // padding stays zero: it pads the NORMALISED image
                 v.x = fmaf(v.x, sc.x, sh.x);
                 v.y = fmaf(v.y, sc.y, sh.y);
                 v.z = fmaf(v.z, sc.z, sh.z);
                 v.w = fmaf(v.w, sc.w, sh.w);
             }
+            s_in[q * D2_PLANE + ly * D2_PITCH + lx] = v;
         }
-        s_in[q * D2_PLANE + ly * D2_PITCH + lx] = v;
     }
     __syncthreads();
 

@@ -89,8 +89,9 @@ __device__ __forceinline__ void epi_cols(const uwir_gemm_args& g, int n_base, in
 }
 // EPI (compile-time epilogue class, chosen by epi_class on the host): EPI_FULL everything; EPI_LEAN no residual / blend /
 // per-sample scale / scatter, and the bias is ALREADY in the accumulators (the kernel initialised them with it: its load
-// overlaps the first K tile instead of standing between the last MFMA and the stores); EPI_RES = EPI_LEAN + a plain
-// fp32 residual.  The lean classes keep the plain 1x1 GEMMs at 4 resident blocks per CU (<= 128 VGPRs).
+// overlaps the first K tile instead of standing between the last MFMA and the stores); EPI_RES = EPI_LEAN + an fp32
+// residual (plain or affine) with nothing non-additive between the bias and it (no activation, no column scale), which
+// therefore ALSO starts out in the accumulators.  The lean classes keep the plain 1x1 GEMMs at 4 resident blocks per CU (<= 128 VGPRs).
 #define EPI_FULL 0
 #define EPI_LEAN 1
 #define EPI_RES 2
@@ -136,11 +137,11 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
 #pragma unroll
         for (int j = 0; j < TN; ++j) v[j] *= t[j];
     }
-    if (EPI != EPI_LEAN && g.res) {
+    if (EPI == EPI_FULL && g.res) {
         f32x4 r[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) r[j] = ld(g.res + out_row * g.ldr, j);
-        if (EPI == EPI_FULL && g.res_scale) {
+        if (g.res_scale) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const f32x4 s4 = ld(g.res_scale + (size_t)b * N, j), h4 = ld(g.res_shift + (size_t)b * N, j);
@@ -170,19 +171,10 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
 }
 
 static int epi_class(const uwir_gemm_args& g) {
-    if (g.blend_out || g.batch_scale || g.store_mode != 0 || !g.out || g.res_scale) return EPI_FULL;
-    return g.res ? EPI_RES : EPI_LEAN;
-}
-// accumulator start values of a lean-class kernel: the bias of the lane's channels (see gemm_epilogue for the mapping)
-template <int TM, int TN>
-__device__ __forceinline__ void acc_init_bias(const uwir_gemm_args& g, f32x4 (&acc)[TM][TN], int n_base, int fq) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n_base + fq * 16 + j * 4;
-        const f32x4 b4 = (g.bias && n < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = b4;
-    }
+    if (g.blend_out || g.batch_scale || g.store_mode != 0 || !g.out) return EPI_FULL;
+    if (!g.res) return EPI_LEAN;
+    // (an affine residual's per-image scale / shift must be one vector per 128-row tile)
+    return (g.act == UWIR_ACT_NONE && !g.col_scale && (!g.res_scale || (g.OH * g.OW) % 128 == 0)) ? EPI_RES : EPI_FULL;
 }
 template <int TM, int TN, int EPI = EPI_FULL>
 __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], const int (&mrow)[TM],
@@ -474,7 +466,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 // NBUF = 1: load -> compute per tile (32 KiB LDS, 4 blocks / CU): twice the resident blocks hide more latency than
 // the intra-block overlap does (see launch_gemm) -- this is the variant in use.
 template <int NBUF, int EPI = EPI_FULL>
-__global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
+__global__ void __launch_bounds__(256, (EPI == EPI_LEAN ? 4 : EPI == EPI_RES ? 3 : 2)) gemm_bf16_glds_kernel(GemmP p) {
     constexpr int BM = 128, BN = 128, BK = 64, TM = 4, TN = 4;
     constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
     __shared__ __attribute__((aligned(1024))) char smem[2 * NBUF * TILE_BYTES];  // [buf][A|B]
@@ -529,7 +521,43 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     const int fr = lane & 15, fq = lane >> 4;
-    if (EPI != EPI_FULL) acc_init_bias<TM, TN>(g, acc, n0 + wn0, fq);
+    // lean classes: the accumulators START as bias (+ residual).  The loads are issued here, branch-free (addresses
+    // clamped into the tensor: lanes past an edge compute garbage they never store), and first touched after the first
+    // K tile's barrier, so their latency hides behind that tile's LDS-DMA instead of preceding or following the K loop.
+    f32x4 b4[TN], rs4[TN], rh4[TN];
+    if constexpr (EPI != EPI_FULL) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + wn0 + fq * 16 + j * 4, N - 4);
+            b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_RES) {
+                if (g.res_scale) {
+                    const size_t bo = (size_t)(m0 / (g.OH * g.OW)) * N + n;
+                    rs4[j] = *reinterpret_cast<const f32x4*>(g.res_scale + bo);
+                    rh4[j] = *reinterpret_cast<const f32x4*>(g.res_shift + bo);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = *reinterpret_cast<const f32x4*>(g.res + (size_t)min(m0 + wm0 + i * 16 + fr, M - 1) * g.ldr + n);
+            }
+        }
+    }
+    auto acc_start = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (EPI == EPI_RES) {
+                    if (g.res_scale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(acc[i][j][e], rs4[j][e], rh4[j][e]);
+                    }
+                    acc[i][j] += b4[j];
+                } else {
+                    acc[i][j] = b4[j];
+                }
+            }
+    };
     // fragment byte offsets inside a tile: row*128 + ((chunk ^ (row&7)) * 16); row&7 == fr&7 for every i
     int a_off[TM], b_off[TN];
 #pragma unroll
@@ -572,7 +600,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmP p) {
             __syncthreads();
         }
     } else {
-        for (int kt = kt0; kt < kt1; ++kt) {
+        stage(0, kt0);
+        __syncthreads();
+        if constexpr (EPI != EPI_FULL) acc_start();
+        compute(0);
+        __syncthreads();
+        for (int kt = kt0 + 1; kt < kt1; ++kt) {
             stage(0, kt);
             __syncthreads();
             compute(0);
