@@ -354,10 +354,68 @@ def teacher_case() -> None:
           "conf", {n: store[f"{n}_confidence"].mean() for n in cfgs})
 
 
+def enhance_inputs():
+    """Seeded inputs of the f3 cases: a smooth colour field + texture + a few saturated / negative pixels."""
+    g = torch.Generator().manual_seed(71)
+    h, w = 40, 56
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+    base = torch.stack([0.25 + 0.5 * xx * yy, 0.55 - 0.3 * xx + 0.2 * torch.sin(6 * yy), 0.6 - 0.4 * yy * yy])
+    img = base + 0.08 * torch.randn(3, h, w, generator=g)
+    img[:, 3, 5] = 1.3
+    img[:, 30, 40] = -0.2
+    other = torch.rand(3, h, w, generator=g)
+    small = (base[:, ::2, ::2][:, :18, :26] + 0.05 * torch.randn(3, 18, 26, generator=g)).contiguous()
+    return img.contiguous(), other, small
+
+
+def enhance_case() -> None:
+    """rl/uiep_cwgr_ops.py, rl/uiqm_uciqe.py, rl/infer_adapt.py imported unmodified; `cv2` is absent here, an empty
+    module object satisfies the import statement (none of the functions called below touches it)."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from underwater_ir.rl import infer_adapt as ia
+    from underwater_ir.rl import uiep_cwgr_ops as ops
+    from underwater_ir.rl import uiqm_uciqe as qm
+    img, other, small = enhance_inputs()
+    store = {"img": img.numpy(), "other": other.numpy(), "small": small.numpy()}
+    with torch.no_grad():
+        store["gamma_0p7"] = ops.gamma_correction(img, 0.7).numpy()
+        store["gamma_2p2"] = ops.gamma_correction(img, 2.2).numpy()
+        store["gamma_floor"] = ops.gamma_correction(img, -1.0).numpy()
+        store["mix_0p3"] = ops.lf_hf_mix(img, other, 0.3).numpy()
+        store["mix_1p0"] = ops.lf_hf_mix(img, other, 1.0).numpy()
+        store["wd_1p0"] = ops.wavelet_denoise(img).numpy()
+        store["wd_2p5"] = ops.wavelet_denoise(img, threshold_scale=2.5).numpy()
+        store["wd_f64"] = ops.wavelet_denoise(img.double()).numpy()
+        p1, i1 = img[:1].contiguous(), other[:1].contiguous() * 0.5 + img[1:2] * 0.5
+        store["gf_p"], store["gf_i"] = p1.numpy(), i1.numpy()
+        store["gf_r4"] = ops.guided_filter(p1, i1).numpy()
+        store["gf_r2"] = ops.guided_filter(p1, i1, radius=2, eps=1e-2).numpy()
+        store["gf_self_f64"] = ops.guided_filter(p1.double(), p1.double()).numpy()
+        try:
+            ops.guided_filter(img, img)
+            store["gf_rgb_raises"] = np.bool_(False)
+        except RuntimeError:
+            store["gf_rgb_raises"] = np.bool_(True)
+        store["msr_small_default"] = ops.multi_scale_retinex(small).numpy()          # 91, 481, 1501-tap kernels
+        store["msr_img_s"] = ops.multi_scale_retinex(img, sigmas=(1.5, 4.0)).numpy()
+        store["msr_img_f64"] = ops.multi_scale_retinex(img.double(), sigmas=(2.0, 9.0, 15.0)).numpy()
+        u8 = qm._image_to_numpy(img)
+        store["img_u8"] = u8
+        store["uicm"] = np.float64(qm.compute_uicm(u8))
+        store["sharpness"] = np.float64(ia.compute_sharpness(img[None]))
+        store["sharpness_f64"] = np.float64(ia.compute_sharpness(img[None].double()))
+        store["hist_mean"] = np.float64(float(img[None].mean()))
+        store["hist_std"] = np.float64(float(img[None].std()))
+    np.savez_compressed(os.path.join(HERE, "enhance.npz"), **store)
+    print("enhance: uicm", float(store["uicm"]), "sharpness", float(store["sharpness"]), "gf raises on RGB",
+          bool(store["gf_rgb_raises"]), "msr mean", float(store["msr_small_default"].mean()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics", "teacher", "imgutil"}
+    which = set(sys.argv[1:]) or {"dwt", "student", "sde", "daclip", "unet", "metrics", "teacher", "imgutil", "enhance"}
     if "dwt" in which:
         dwt_case()
     if "student" in which:
@@ -377,3 +435,5 @@ if __name__ == "__main__":
         teacher_case()
     if "imgutil" in which:
         imgutil_case()
+    if "enhance" in which:
+        enhance_case()
