@@ -313,6 +313,37 @@ int uwir_teacher_heads(const uwir_teacher_args* args, uwir_stream_t stream);
  * probs / workspace fields of args. */
 int uwir_guided_crf(const uwir_teacher_args* args, const float* probs_in, const float* confidence_in, uwir_stream_t stream);
 
+/* ---- the RL adapter's enhancement operators and state features that need no OpenCV -------
+ * Images are planar CHW fp32 device buffers, as the reference passes them.  (The OpenCV-backed functions of the same
+ * files -- histogram_equalization, clahe_equalization, compute_uism / uiconm / uciqe / uiqm -- are not provided.)
+ * rl/uiep_cwgr_ops.py:114-116 gamma_correction: out = clamp(x, 0, 1) ** max(gamma, 1e-3). */
+int uwir_gamma_correction(const float* x, float* out, size_t n, float gamma, uwir_stream_t stream);
+/* rl/uiep_cwgr_ops.py:119-120 lf_hf_mix: out = clamp(alpha * high + (1 - alpha) * low, 0, 1), rounded as the fp32
+ * tensor expression rounds (bit-exact). */
+int uwir_lf_hf_mix(const float* low, const float* high, double alpha, float* out, size_t n, uwir_stream_t stream);
+/* rl/uiep_cwgr_ops.py:46-59 wavelet_denoise on a (C, H, W) image, H and W even: one Haar level, per detail band
+ * (all channels together) soft threshold scale * (median|c| / 0.6745)^2 / (sqrt(mean c^2) + 1e-6) with torch.median's
+ * lower-middle element found exactly, inverse Haar.  workspace 256-byte aligned. */
+size_t uwir_wavelet_denoise_workspace_bytes(int C, int H, int W);
+int uwir_wavelet_denoise(const float* x, int C, int H, int W, float threshold_scale, float* out, void* workspace,
+                         size_t workspace_bytes, uwir_stream_t stream);
+/* rl/uiep_cwgr_ops.py:62-86 guided_filter for ONE channel (H, W) -- the reference's (1, 1, k, k) box kernel at groups=1
+ * raises on anything else -- zero-padded (2 radius + 1)^2 box means, radius <= 16. */
+size_t uwir_guided_filter_workspace_bytes(int H, int W);
+int uwir_guided_filter(const float* input, const float* guidance, int H, int W, int radius, float eps, float* out,
+                       void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+/* rl/uiep_cwgr_ops.py:89-111 multi_scale_retinex on (C, H, W); sigmas is a HOST array of nsig values.  The reference's
+ * 2-D normalised Gaussian of size 2 ceil(3 sigma) + 1 is applied as its two exact 1-D factors, zero padded. */
+size_t uwir_multi_scale_retinex_workspace_bytes(int C, int H, int W);
+int uwir_multi_scale_retinex(const float* x, int C, int H, int W, const double* sigmas, int nsig, float* out,
+                             void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+/* State features of rl/infer_adapt.py:62-68 build_state on a (C, H, W) image, written to 4 DEVICE doubles:
+ * out4[0] = compute_uicm (rl/uiqm_uciqe.py:13-21; on the uint8-quantised image, C must be 3, else NaN),
+ * out4[1], out4[2] = mean and unbiased std over every element, out4[3] = compute_sharpness (:52-59). */
+size_t uwir_enhance_state_workspace_bytes(void);
+int uwir_enhance_state(const float* img, int C, int H, int W, double* out4, void* workspace, size_t workspace_bytes,
+                       uwir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,16 @@ _SIGS = {
     "uwir_teacher_heads_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_teacher_heads": (ci, [C.POINTER(TeacherArgs), vp]),
     "uwir_guided_crf": (ci, [C.POINTER(TeacherArgs), vp, vp, vp]),
+    "uwir_gamma_correction": (ci, [vp, vp, sz, cf, vp]),
+    "uwir_lf_hf_mix": (ci, [vp, vp, C.c_double, vp, sz, vp]),
+    "uwir_wavelet_denoise_workspace_bytes": (sz, [ci, ci, ci]),
+    "uwir_wavelet_denoise": (ci, [vp, ci, ci, ci, cf, vp, vp, sz, vp]),
+    "uwir_guided_filter_workspace_bytes": (sz, [ci, ci]),
+    "uwir_guided_filter": (ci, [vp, vp, ci, ci, ci, cf, vp, vp, sz, vp]),
+    "uwir_multi_scale_retinex_workspace_bytes": (sz, [ci, ci, ci]),
+    "uwir_multi_scale_retinex": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), ci, vp, vp, sz, vp]),
+    "uwir_enhance_state_workspace_bytes": (sz, []),
+    "uwir_enhance_state": (ci, [vp, ci, ci, ci, vp, vp, sz, vp]),
     "uwir_add_rows": (ci, [vp, sz, vp, sz, vp, sz, ci, ci, vp]),
     "uwir_patchify": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, sz, vp]),
 }
