@@ -176,6 +176,56 @@ static int epi_class(const uwir_gemm_args& g) {
     // (an affine residual's per-image scale / shift must be one vector per 128-row tile)
     return (g.act == UWIR_ACT_NONE && !g.col_scale && (!g.res_scale || (g.OH * g.OW) % 128 == 0)) ? EPI_RES : EPI_FULL;
 }
+// Lean classes: the accumulators START as bias (+ residual).  epi_start_issue issues the loads branch-free (addresses
+// clamped into the tensor: lanes past an edge compute garbage they never store) BEFORE the first K tile's loads;
+// epi_start_apply folds them into the accumulators after that tile's barrier, so their latency hides behind the tile
+// instead of preceding or following the K loop.  Rows are linear (m_base + i*16 + fr); an affine residual's per-image
+// vectors are taken at row m_tile0 (epi_class guarantees one image per 128-row tile).
+template <int TN>
+struct EpiStart {
+    f32x4 b4[TN], rs4[TN], rh4[TN];
+};
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epi_start_issue(const uwir_gemm_args& g, f32x4 (&acc)[TM][TN], EpiStart<TN>& st, int m_base,
+                                                int M, int m_tile0, int n_base, int fr, int fq) {
+    if constexpr (EPI != EPI_FULL) {
+        const int N = g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n_base + fq * 16 + j * 4, N - 4);
+            st.b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_RES) {
+                if (g.res_scale) {
+                    const size_t bo = (size_t)(m_tile0 / (g.OH * g.OW)) * N + n;
+                    st.rs4[j] = *reinterpret_cast<const f32x4*>(g.res_scale + bo);
+                    st.rh4[j] = *reinterpret_cast<const f32x4*>(g.res_shift + bo);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = *reinterpret_cast<const f32x4*>(g.res + (size_t)min(m_base + i * 16 + fr, M - 1) * g.ldr + n);
+            }
+        }
+    }
+}
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epi_start_apply(const uwir_gemm_args& g, f32x4 (&acc)[TM][TN], const EpiStart<TN>& st) {
+    if constexpr (EPI != EPI_FULL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (EPI == EPI_RES) {
+                    if (g.res_scale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(acc[i][j][e], st.rs4[j][e], st.rh4[j][e]);
+                    }
+                    acc[i][j] += st.b4[j];
+                } else {
+                    acc[i][j] = st.b4[j];
+                }
+            }
+    }
+}
 template <int TM, int TN, int EPI = EPI_FULL>
 __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32x4 (&acc)[TM][TN], const int (&mrow)[TM],
                                               const int (&mcnt)[TM], int n_base, int fr, int fq) {
@@ -235,7 +285,7 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
 }
 
 
-template <typename TC, typename TA, int BN, int NB>
+template <typename TC, typename TA, int BN, int NB, int EPI = EPI_FULL>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
     using Cfg = MmaCfg<TC>;
     constexpr int BM = 128, BK = Cfg::BK, EPC = Cfg::EPC, BKP = BK + Cfg::PAD, CPR = BK / EPC;
@@ -395,6 +445,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
     const int fr = lane & 15, fq = lane >> 4;
+    EpiStart<TN> est;
+    epi_start_issue<TM, TN, EPI>(g, acc, est, m0 + wm0, M, m0, n0 + wn0, fr, fq);   // (lean classes are linear-row launches)
 
     auto compute = [&](int buf) {
 #pragma unroll
@@ -444,6 +496,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
             store_lds(0);
             __syncthreads();
             if (kt + 1 < nk) load_regs(kt + 1);
+            if (kt == 0) epi_start_apply<TM, TN, EPI>(g, acc, est);
             compute(0);
             __syncthreads();
         }
@@ -451,7 +504,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(GemmP p) {
 
     int mrow[TM], mcnt[TM];
     linear_rows<TM>(mrow, mcnt, m0 + wm0, M);
-    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
+    gemm_epilogue<TM, TN, EPI>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -521,43 +574,8 @@ __global__ void __launch_bounds__(256, (EPI == EPI_LEAN ? 4 : EPI == EPI_RES ? 3
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     const int fr = lane & 15, fq = lane >> 4;
-    // lean classes: the accumulators START as bias (+ residual).  The loads are issued here, branch-free (addresses
-    // clamped into the tensor: lanes past an edge compute garbage they never store), and first touched after the first
-    // K tile's barrier, so their latency hides behind that tile's LDS-DMA instead of preceding or following the K loop.
-    f32x4 b4[TN], rs4[TN], rh4[TN];
-    if constexpr (EPI != EPI_FULL) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = min(n0 + wn0 + fq * 16 + j * 4, N - 4);
-            b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_RES) {
-                if (g.res_scale) {
-                    const size_t bo = (size_t)(m0 / (g.OH * g.OW)) * N + n;
-                    rs4[j] = *reinterpret_cast<const f32x4*>(g.res_scale + bo);
-                    rh4[j] = *reinterpret_cast<const f32x4*>(g.res_shift + bo);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][j] = *reinterpret_cast<const f32x4*>(g.res + (size_t)min(m0 + wm0 + i * 16 + fr, M - 1) * g.ldr + n);
-            }
-        }
-    }
-    auto acc_start = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (EPI == EPI_RES) {
-                    if (g.res_scale) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(acc[i][j][e], rs4[j][e], rh4[j][e]);
-                    }
-                    acc[i][j] += b4[j];
-                } else {
-                    acc[i][j] = b4[j];
-                }
-            }
-    };
+    EpiStart<TN> est;
+    epi_start_issue<TM, TN, EPI>(g, acc, est, m0 + wm0, M, m0, n0 + wn0, fr, fq);
     // fragment byte offsets inside a tile: row*128 + ((chunk ^ (row&7)) * 16); row&7 == fr&7 for every i
     int a_off[TM], b_off[TN];
 #pragma unroll
@@ -602,7 +620,7 @@ __global__ void __launch_bounds__(256, (EPI == EPI_LEAN ? 4 : EPI == EPI_RES ? 3
     } else {
         stage(0, kt0);
         __syncthreads();
-        if constexpr (EPI != EPI_FULL) acc_start();
+        epi_start_apply<TM, TN, EPI>(g, acc, est);
         compute(0);
         __syncthreads();
         for (int kt = kt0 + 1; kt < kt1; ++kt) {
@@ -916,10 +934,14 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     }
     // one LDS buffer + register prefetch (NB = 1): half the LDS, more resident blocks; measured 13.0 -> 11.5 ms on the
     // IR-SDE UNet step (B=8, 256^2, bf16) against the double-buffered form, neutral on the student
-    if (bn == 64)
-        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 64, 1>), dim3(p.nblocks), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, 128, 1>), dim3(p.nblocks), dim3(256), 0, stream, p);
+// (no EPI_RES variants here: the register-staged loop plus residual start values reach 257 VGPRs at BN = 128)
+#define UWIR_LAUNCH_GENERIC(BN_)                                                                                         \
+    if (epi_class(p.a) == EPI_LEAN)                                                                                      \
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, BN_, 1, EPI_LEAN>), dim3(p.nblocks), dim3(256), 0, stream, p);      \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((conv_gemm_kernel<TC, TA, BN_, 1, EPI_FULL>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    if (bn == 64) { UWIR_LAUNCH_GENERIC(64) } else { UWIR_LAUNCH_GENERIC(128) }
+#undef UWIR_LAUNCH_GENERIC
     UWIR_LAUNCH_CHECK("conv_gemm");
     return UWIR_OK;
 }
