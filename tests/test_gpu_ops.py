@@ -223,6 +223,40 @@ def test_conv_gemm_splitk(ops, shape):
     assert err(ob, torch.nn.functional.gelu(A.double() @ Wt.double().T + bias.double())) < 3e-2
 
 
+@pytest.mark.parametrize("geom", [(3, 16, 24, 192, 128), (1, 10, 13, 200, 192), (2, 8, 16, 576, 64), (1, 16, 17, 72, 64)])
+def test_conv_gemm_epilogue_classes(ops, geom):
+    """The compile-time epilogue classes of the 1x1 GEMM kernels (plain: bias / per-sample bias / activation / column
+    scale with the bias as accumulator start; residual: + fp32 residual, plain or affine, also as start value; full:
+    everything else) against one fp64 formula, on shapes with ragged M and N tiles, images that do and do not fill
+    whole 128-row tiles (the affine residual falls back to the full class when they do not), bf16 and fp32 inputs."""
+    b, h, w, n, k = geom
+    m = b * h * w
+    g = torch.Generator().manual_seed(77)
+    wt = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16().cuda()
+    bias, cs = torch.randn(n, generator=g).cuda(), (torch.rand(n, generator=g) + 0.5).cuda()
+    bb = torch.randn(b, n, generator=g).cuda()
+    res = torch.randn(m, n, generator=g).cuda()
+    rs, rh = (torch.rand(b, n, generator=g) + 0.5).cuda(), torch.randn(b, n, generator=g).cuda()
+    img = torch.arange(m, device="cuda") // (h * w)
+    for a_dt in (torch.bfloat16, torch.float32):
+        a = torch.randn(m, k, generator=g).bfloat16().to(a_dt).cuda()      # bf16-representable either way
+        acc = a.double() @ wt.double().T
+        cases = {
+            "lean": (dict(bias=bias, batch_bias=bb, act=ops.ACT_GELU, col_scale=cs),
+                     torch.nn.functional.gelu(acc + bias.double() + bb.double()[img]) * cs.double()),
+            "lean_nobias": (dict(), acc),
+            "res": (dict(bias=bias, res=res), acc + bias.double() + res.double()),
+            "res_affine": (dict(bias=bias, batch_bias=bb, res=res, res_scale=rs, res_shift=rh),
+                           acc + bias.double() + bb.double()[img] + res.double() * rs.double()[img] + rh.double()[img]),
+            "full_act_res": (dict(bias=bias, act=ops.ACT_RELU, res=res), torch.relu(acc + bias.double()) + res.double()),
+        }
+        for name, (kw, want) in cases.items():
+            for odt, tol in ((torch.float32, 2e-4), (torch.bfloat16, 2.0 ** -8 * float(want.abs().max()))):   # half a bf16 ulp
+                out = torch.full((m, n), float("nan"), device="cuda", dtype=odt)
+                ops.conv_gemm(a, wt, out, B=b, H=h, W=w, C_=k, N=n, **kw)
+                assert err(out, want) < tol, (name, a_dt, odt)
+
+
 def test_conv_gemm_rejects_bad_arguments(ops):
     x = torch.zeros(16, 12, device="cuda")
     w = torch.zeros(8, 12, device="cuda")
