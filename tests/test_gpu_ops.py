@@ -101,6 +101,14 @@ def test_linear_and_fold(ops):
         y = torch.empty(3, 37, device="cuda")
         ops.linear(x.cuda(), w.cuda(), bias.cuda(), y, act)
         assert err(y, fn(F.linear(x.double(), w.double(), bias.double()))) < 2e-5
+    # more rows than one pass holds, long feature vectors (fewer rows per pass), a column slice of a wider matrix as x
+    for (b, i, o) in ((40, 512, 70), (5, 3000, 9), (16, 768, 1500), (19, 512, 2051), (2, 12288, 3)):   # 3rd, 4th: wide kernel
+        xw = torch.randn(b, i + 8, generator=g).cuda()
+        w2, b2 = (torch.randn(o, i, generator=g) * i ** -0.5).cuda(), torch.randn(o, generator=g).cuda()
+        y2 = torch.full((b, o + 3), 7.0, device="cuda")
+        ops.linear(xw[:, 4:4 + i], w2, b2, y2[:, :o])
+        assert err(y2[:, :o], F.linear(xw[:, 4:4 + i].double(), w2.double(), b2.double())) < 2e-5
+        assert bool((y2[:, o:] == 7.0).all())
     a, s, cw = (torch.randn(2, 12, generator=g).cuda() for _ in range(3))
     os_, oh = torch.empty_like(a), torch.empty_like(a)
     ops.chan_attn_fold(a, s, cw, os_, oh)

@@ -384,7 +384,14 @@ extern "C" int uwir_chan_attn_fold(const float* a, const float* s, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// tiny linear: one wave per output element (b, o)
+// tiny linear y[b, o] = act(x[b, :] . W[o, :] + bias[o]) for a handful of rows b.
+// linear_kernel: one wave per output element (b, o) -- the launch-latency-sized calls (a few thousand outputs).
+// linear_wide_kernel: cond / time embeddings -> all the AdaLN / gate / ResBlock vectors of a forward in one call
+// (B = 16, O = 19200, I = 512 in the student).  There the weight matrix is the only real traffic (39 MB), so it is read
+// ONCE: a wave owns 4 output columns and keeps their weight elements in registers while it walks up to 16 rows of x
+// staged in LDS (one wave per element re-reads every weight row B times: 0.14-0.21 ms; this form 0.063 ms, now bound by
+// its 64 butterfly reductions per wave, not by the stream; on a small call it costs 25 us instead of 4, hence two kernels).  Per element both accumulate
+// in the same order (lane-strided partial sums, then the xor butterfly): bit-identical results.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x, int ldx, int B, int I,
                                                      const float* __restrict__ W, const float* __restrict__ bias,
@@ -405,14 +412,73 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     }
 }
 
+#define LIN_OW 4    // output columns per wave
+template <int LIN_BT>   // rows of x per pass (LDS: LIN_BT x I floats)
+__global__ void __launch_bounds__(256) linear_wide_kernel(const float* __restrict__ x, int ldx, int B, int I,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          int O, int act, float* __restrict__ y, int ldy) {
+    extern __shared__ float sx[];   // [LIN_BT][I]
+    const int wave = threadIdx.x / UWIR_WAVE, lane = threadIdx.x % UWIR_WAVE;
+    const int o0 = (blockIdx.x * 4 + wave) * LIN_OW;
+    const float* wr[LIN_OW];
+#pragma unroll
+    for (int k = 0; k < LIN_OW; ++k) wr[k] = W + (size_t)min(o0 + k, O - 1) * I;
+    for (int b0 = 0; b0 < B; b0 += LIN_BT) {
+        const int nb = min(LIN_BT, B - b0);
+        __syncthreads();
+        for (int ii = threadIdx.x; ii < I; ii += 256) {   // LIN_BT independent loads in flight, then the LDS stores
+            float v[LIN_BT];
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) v[t] = t < nb ? x[(size_t)(b0 + t) * ldx + ii] : 0.f;
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) sx[t * I + ii] = v[t];
+        }
+        __syncthreads();
+        float acc[LIN_OW][LIN_BT];
+#pragma unroll
+        for (int k = 0; k < LIN_OW; ++k)
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) acc[k][t] = 0.f;
+        for (int i = lane; i < I; i += UWIR_WAVE) {
+            float w[LIN_OW];
+#pragma unroll
+            for (int k = 0; k < LIN_OW; ++k) w[k] = wr[k][i];
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) {
+                const float xv = sx[t * I + i];
+#pragma unroll
+                for (int k = 0; k < LIN_OW; ++k) acc[k][t] = fmaf(xv, w[k], acc[k][t]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LIN_OW; ++k)
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) {
+                float a = acc[k][t];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0 && t < nb && o0 + k < O) {
+                    if (bias) a += bias[o0 + k];
+                    y[(size_t)(b0 + t) * ldy + o0 + k] = act_apply(a, act);
+                }
+            }
+    }
+}
+
 extern "C" int uwir_linear(const float* x, int ldx, int B, int I, const float* W, const float* bias, int O, int act,
                            float* y, int ldy, uwir_stream_t stream) {
     UWIR_CHECK(x && W && y, "linear: null pointer");
     UWIR_CHECK(B > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "linear: bad shape");
-    size_t waves = (size_t)B * O;
-    UWIR_CHECK(waves < (1u << 28), "linear: too many outputs");
-    hipLaunchKernelGGL(linear_kernel, dim3((unsigned)ceil_div_sz(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       B, I, W, bias, O, act, y, ldy);
+    hipStream_t s = (hipStream_t)stream;
+    if (B >= 8 && I <= 768 && (size_t)O * I >= (1u << 20)) {   // >= 4 MB of weights, <= 48 KiB of LDS
+        hipLaunchKernelGGL(linear_wide_kernel<16>, dim3(ceil_div(O, 4 * LIN_OW)), dim3(256), (size_t)16 * I * sizeof(float), s, x,
+                           ldx, B, I, W, bias, O, act, y, ldy);
+    } else {
+        size_t waves = (size_t)B * O;
+        UWIR_CHECK(waves < (1u << 28), "linear: too many outputs");
+        hipLaunchKernelGGL(linear_kernel, dim3((unsigned)ceil_div_sz(waves, 4)), dim3(256), 0, s, x, ldx, B, I, W, bias, O, act,
+                           y, ldy);
+    }
     UWIR_LAUNCH_CHECK("linear");
     return UWIR_OK;
 }
