@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/exp/store_pattern tools/exp/store_pattern.hip ; run on the GPU box.
 // experiment: what do the GEMM epilogue's output stores cost by pattern?  (not part of the library)
 #include <hip/hip_runtime.h>
 #include <cstdio>
