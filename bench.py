@@ -68,6 +68,8 @@ def main() -> None:
     ap.add_argument("--sde-steps", type=int, default=100)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="encode and consumer back to back on one stream (default: encode of step k+1 on a second stream)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the ranks rendezvous over gloo "
                          "(checks the barrier / max-over-ranks / rank-0 reporting logic; the number is not a result)")
@@ -106,8 +108,10 @@ def main() -> None:
     clip_in = torch.randn(args.batch, 3, 224, 224, generator=torch.Generator().manual_seed(7 + rank))
     x, m, clip_in = x.cuda(), m.cuda(), clip_in.cuda()
 
-    def step():
-        _, z_d = clip.encode_image(clip_in, control=True)   # U/test.py:114-117: degra_features condition the net
+    # a step = encode(clip view) -> consume(features); U/test.py:114-117: degra_features condition the net
+    enc_in = clip_in
+
+    def consume(img_f, z_d):
         return model(x, z_d, m)
 
     mp_per_step = args.batch * args.size * args.size / 1e6
@@ -118,8 +122,9 @@ def main() -> None:
         restorer = TiledRestorer(model, tile=256, halo=32, max_batch=30)
         m1, c1 = m[:1].contiguous(), clip_in[:1].contiguous()
 
-        def step():  # noqa: F811
-            _, z_d = clip.encode_image(c1, control=True)
+        enc_in = c1
+
+        def consume(img_f, z_d):  # noqa: F811
             return restorer(frame, z_d, m1)
         mp_per_step = 1080 * 1920 / 1e6
         wl_name = (f"BASELINE configs[2]: 1920x1080 frame, 60 halo windows of 256 px (32-px halo), DA-CLIP z_d, "
@@ -138,8 +143,9 @@ def main() -> None:
         sde.set_mu(mu)
         cin = clip_in[:Bs].contiguous()
 
-        def step():  # noqa: F811
-            img_f, deg_f = clip.encode_image(cin, control=True)
+        enc_in = cin
+
+        def consume(img_f, deg_f):  # noqa: F811
             xt = sde.noise_state(mu)
             return sde.reverse_posterior(xt, text_context=deg_f, image_context=img_f)
         mp_per_step = Bs * args.size * args.size / 1e6
@@ -150,22 +156,39 @@ def main() -> None:
         xd, _, md = synth_student_inputs(Bd, 512, 512, 512, 10, mask_hw=(7, 7), seed=99 + rank)
         xd, md, cd = xd.cuda(), md.cuda(), clip_in[:Bd].contiguous()
 
-        def step():  # noqa: F811
-            _, z_d = clip.encode_image(cd, control=True)
+        enc_in = cd
+
+        def consume(img_f, z_d):  # noqa: F811
             return model(xd, z_d, md)
         mp_per_step = Bd * 512 * 512 / 1e6
         wl_name = f"BASELINE configs[4]: 512x512 images, {Bd}/GPU per step, DA-CLIP z_d, {args.precision}"
 
-    for _ in range(args.warmup):
-        step()
+    # Every step runs BOTH halves inside the timed region.  By default the encode of step k+1 is enqueued on a second
+    # HIP stream before the consumer of step k (pipeline.ConditioningPrefetcher): its ~200 small launches fill CUs the
+    # consumer's kernels leave idle.  --no-overlap runs the two halves back to back on one stream.
+    from underwater_image_restoration_amd.pipeline import ConditioningPrefetcher
+    prefetch = None if args.no_overlap else ConditioningPrefetcher(clip)
+
+    def run_steps(k: int) -> None:
+        if prefetch is None:
+            for _ in range(k):
+                consume(*clip.encode_image(enc_in, control=True))
+            return
+        handle = prefetch.launch(enc_in) if k > 0 else None
+        for i in range(k):
+            feats = prefetch.take(handle)
+            if i + 1 < k:
+                handle = prefetch.launch(enc_in)
+            consume(*feats)
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ops.event_timing(True)  # HIP events around the main kernel of every flash-attention call (uwir_flash_attn_probe)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -211,6 +234,7 @@ def main() -> None:
                                    f"NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
                                    f"{args.precision} MFMA compute, masks (10,7,7)",
                        "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
+                       "encode_overlap": "none" if args.no_overlap else "next step's encode on a second HIP stream",
                        "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
                        "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -1,0 +1,44 @@
+"""GPU: the two-stream dataset loop (pipeline.restore_stream / ConditioningPrefetcher) returns, batch for batch, exactly
+what encode -> restore back to back on one stream returns (no shared scratch between the streams, hand-over by event)."""
+import pytest
+import torch
+
+from underwater_image_restoration_amd.synth import (daclip_vision_param_shapes, student_param_shapes, synth_state_dict,
+                                                    synth_student_inputs)
+
+pytestmark = pytest.mark.gpu
+MK = dict(base_channels=32, num_levels=3, blocks_per_level=1, cond_dim=512, num_masks=4, num_degradation_types=5)
+
+
+def test_restore_stream_equals_sequential():
+    from underwater_image_restoration_amd.daclip import DaCLIPVision
+    from underwater_image_restoration_amd.pipeline import ConditioningPrefetcher, restore_stream
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    model = NAFNetWFIGate(**MK, precision="bf16")
+    model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=0))
+    model = model.cuda().eval()
+    clip = DaCLIPVision(precision="bf16")
+    clip.load_state_dict(synth_state_dict(daclip_vision_param_shapes(), seed=1))
+    clip = clip.cuda().eval()
+    batches = []
+    for i in range(4):
+        x, _, m = synth_student_inputs(2, 128, 128, 512, 4, mask_hw=(7, 7), seed=40 + i)
+        cin = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(60 + i))
+        batches.append((x.cuda(), cin.cuda(), m.cuda()))
+    want = []
+    for x, cin, m in batches:
+        _, z = clip.encode_image(cin, control=True)
+        want.append(model(x, z, m)[0].clone())
+    torch.cuda.synchronize()
+    for _ in range(2):   # twice: the second pass reuses every buffer of the first
+        got = [out[0].clone() for out in restore_stream(clip, model, batches)]
+        torch.cuda.synchronize()
+        assert len(got) == 4
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+    assert list(restore_stream(clip, model, [])) == []
+    pf = ConditioningPrefetcher(clip)
+    h = pf.launch(batches[0][1])
+    with pytest.raises(RuntimeError):
+        pf.launch(batches[1][1])                 # one encode in flight: the encoder's buffers are not double-buffered
+    pf.take(h)

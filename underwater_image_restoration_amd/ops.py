@@ -102,7 +102,8 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], y: to
     _lib.check(lib.uwir_linear(_p(x), _ld(x), B, I, _p(W), _p(bias), O, act, _p(y), _ld(y), _stream()), "linear")
 
 
-_GEMM_WS = {}    # per-device split-K scratch (stream-ordered reuse; see uwir_gemm_args.workspace)
+_GEMM_WS = {}    # split-K scratch per (device, stream): calls that share one must be ordered on one stream
+                 # (uwir_gemm_args.workspace), so every stream that runs this library gets its own
 _SPLITK = True   # tools/: False = never lend the scratch
 
 
@@ -147,10 +148,11 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
     if _SPLITK and -(-(B * g.OH * g.OW) // 128) * -(-N // 128) < 128 and KH == 1 and g.a_dtype == BF16:
         need = int(lib.uwir_conv_gemm_workspace_bytes(C.byref(g)))   # few output tiles: lend the split-K scratch
         if need:
-            ws = _GEMM_WS.get(A.device)
+            key = (A.device, _stream())
+            ws = _GEMM_WS.get(key)
             if ws is None or ws.numel() * 4 < need:
                 ws = torch.zeros(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=A.device)  # counters start at 0
-                _GEMM_WS[A.device] = ws
+                _GEMM_WS[key] = ws
             g.workspace, g.workspace_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
 
@@ -173,15 +175,17 @@ _PACKED = True  # tools/: False keeps the workspace at the header size, i.e. the
 
 
 def _attn_workspace(dev, B: int, n: int, heads: int, hd: int, nv: int):
-    """Per-device scratch for the bf16 fast path, grown on demand: max_k |k|^2 per (b, head) + block marks, and for
-    long hd 16 / 32 sequences the packed K / V^T streams (uwir.h)."""
+    """Scratch for the bf16 fast path per (device, stream), grown on demand: max_k |k|^2 per (b, head) + block marks,
+    and for long hd 16 / 32 sequences the packed K / V^T streams (uwir.h).  Calls on one stream reuse it in order; a
+    second stream (pipeline.ConditioningPrefetcher) gets its own."""
     lib = _lib.load()
     need = int(lib.uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) if _PACKED
                else lib.uwir_flash_attn_workspace_bytes(B, n, heads))
-    t = _ATTN_WS.get(dev)
+    key = (dev, _stream())
+    t = _ATTN_WS.get(key)
     if t is None or t.numel() * 4 < need:
         t = torch.empty(max(need // 4, 4096), dtype=torch.float32, device=dev)
-        _ATTN_WS[dev] = t
+        _ATTN_WS[key] = t
     return t, need  # the library picks its kernels by the byte count it is GIVEN, not by the buffer's capacity
 
 
