@@ -70,6 +70,8 @@ def main() -> None:
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--no-overlap", action="store_true",
                     help="encode and consumer back to back on one stream (default: encode of step k+1 on a second stream)")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="student: SFFB after WTB on one stream (default: SFFB on a second stream under WTB)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the ranks rendezvous over gloo "
                          "(checks the barrier / max-over-ranks / rank-0 reporting logic; the number is not a result)")
@@ -100,6 +102,7 @@ def main() -> None:
     model = NAFNetWFIGate(**mk, precision=args.precision)
     model.load_state_dict(sd)
     model = model.cuda().eval()
+    model.overlap_branches = not args.serial_branches
     clip_sd = synth_state_dict(daclip_vision_param_shapes(), seed=1)
     clip = DaCLIPVision(precision=args.precision)
     clip.load_state_dict(clip_sd)
@@ -235,6 +238,7 @@ def main() -> None:
                                    f"{args.precision} MFMA compute, masks (10,7,7)",
                        "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
                        "encode_overlap": "none" if args.no_overlap else "next step's encode on a second HIP stream",
+                       "branch_overlap": "none" if args.serial_branches else "SFFB on a second HIP stream under WTB",
                        "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
                        "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -42,3 +42,24 @@ def test_restore_stream_equals_sequential():
     with pytest.raises(RuntimeError):
         pf.launch(batches[1][1])                 # one encode in flight: the encoder's buffers are not double-buffered
     pf.take(h)
+
+
+def test_student_branch_overlap_is_bit_identical():
+    """SFFB on a second stream under WTB (student.overlap_branches) changes scheduling only: identical outputs, alphas and
+    logits, run after run, in both precisions."""
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    for prec in ("bf16", "fp32"):
+        model = NAFNetWFIGate(**MK, precision=prec)
+        model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=3))
+        model = model.cuda().eval()
+        x, z, m = (t.cuda() for t in synth_student_inputs(3, 96, 160, 512, 4, mask_hw=(7, 7), seed=11))
+        assert model.overlap_branches
+        outs = []
+        for flag in (True, False, True):
+            model.overlap_branches = flag
+            o, alphas, logits = model(x, z, m)
+            torch.cuda.synchronize()
+            outs.append((o.clone(), [a.clone() for a in alphas], logits.clone()))
+        for o, alphas, logits in outs[1:]:
+            assert torch.equal(o, outs[0][0]) and torch.equal(logits, outs[0][2])
+            assert all(torch.equal(a, b) for a, b in zip(alphas, outs[0][1]))

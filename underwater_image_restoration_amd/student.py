@@ -66,6 +66,8 @@ class NAFNetWFIGate(nn.Module):
         self.reset_parameters()
         self._pack: Optional[dict] = None
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._streams: dict = {}            # device -> side stream of the SFFB branch
+        self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self) -> None:
@@ -232,6 +234,42 @@ class NAFNetWFIGate(nn.Module):
             self._bufs[key] = t
         return t
 
+    def _side_stream(self, dev) -> "torch.cuda.Stream":
+        st = self._streams.get(dev)
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            self._streams[dev] = st
+        return st
+
+    def _sffb(self, bp: dict, ll: torch.Tensor, B: int, h: int, w: int, cond_all: torch.Tensor, lvl: int):
+        """SpatialFrequencyFusionBlock (sffb.py:44-55) on ll -> (lf, spatial).  Touches only buffers of its own (its
+        LayerNorm workspace included), so it may run on another stream than the WTB branch."""
+        Cc = bp["C"]
+        n, Mr = h * w, B * h * w
+        dev, f32, adt = ll.device, torch.float32, self._pack["adt"]
+        tg = f"L{lvl}"
+        buf = lambda name, cols, dt=f32, zero=False: self._buf(tg + name, Mr, cols, dt, dev, zero)  # noqa: E731
+        small = lambda name, cols: self._buf(tg + name, B, cols, f32, dev)  # noqa: E731
+        ws = self._buf("lnws_sffb", 1, max(ops.ln2d_workspace_bytes(B, n, Cc) // 8, 1), torch.float64, dev)
+        a3, s3 = small("a3", Cc), small("s3", Cc)
+        o, ln_ = bp["lnorm_ss"]
+        ops.ln2d_affine(ll, B, n, Cc, _EPS, bp["lnorm_g"], bp["lnorm_b"], cond_all[:, o:o + ln_], a3, s3, None, None, ws)
+        ms2 = buf("ms2", 3 * Cc, adt)
+        ops.dwconv_ms(ll, B, h, w, Cc, bp["ldw_t"], bp["ldw_b"], ms2, in_scale=a3, in_shift=s3)
+        spatial = buf("spat", Cc)
+        ops.conv_gemm(ms2, bp["lmerge_w"], spatial, B=B, H=h, W=w, C_=3 * Cc, N=Cc, bias=bp["lmerge_b"])
+        amp, ph = buf("amp", Cc), buf("ph", Cc)
+        fws = self._buf("fftws", 1, ops.fft_workspace_bytes(B, h, w, Cc) // 4, f32, dev)
+        ops.fft2_amp_phase(spatial, B, h, w, Cc, amp, ph, fws)
+        amp2, ph2 = buf("amp2", Cc), buf("ph2", Cc)
+        ops.conv_gemm(amp, bp["amp_w"], amp2, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["amp_b"])
+        ops.conv_gemm(ph, bp["ph_w"], ph2, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["ph_b"])
+        sf = amp  # amp is dead: reuse
+        ops.ifft2_polar_add(amp2, ph2, spatial, B, h, w, Cc, sf, fws)
+        lf = buf("lf", Cc)
+        ops.conv_gemm(sf, bp["reproj_w"], lf, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["reproj_b"])
+        return lf, spatial
+
     # ------------------------------------------------------------------ one WFI block
     def _wfi_block(self, bp: dict, x_in: torch.Tensor, B: int, h2: int, w2: int, cond_all: torch.Tensor,
                    gate_in: torch.Tensor, out: torch.Tensor, lvl: int, taps: Optional[dict]) -> torch.Tensor:
@@ -248,6 +286,19 @@ class NAFNetWFIGate(nn.Module):
         ll, hf = buf("ll", Cc), buf("hf", Cw)
         ops.dwt2(x_in, B, h2, w2, Cc, ll, hf)
         ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, n, Cw) // 8, 1), torch.float64, dev)
+
+        # The SFFB branch (on ll) and the WTB branch (on hf) are independent until the CFC: SFFB (FFT passes, C-wide 1x1
+        # convs, a small depthwise conv) is enqueued on a second HIP stream next to WTB.  Measured 0.6 ms of the 57.7 ms
+        # step, bit-identical.  (Releasing it exactly at the attention launch, to hide it in the shadow of that
+        # exp-bound kernel, gains the same 0.6 ms but slows the attention launch itself by 2 %: its blocks fill the
+        # register file, so foreign workgroups only get in as its rounds retire.)
+        side = self._side_stream(dev) if self.overlap_branches else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))   # ll / hf of THIS block are written
+            with torch.cuda.stream(side):
+                lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl)
+                sffb_done = torch.cuda.Event()
+                sffb_done.record(side)
 
         # ---------------- WideTransformerBlock (wtb.py:83-124) on hf
         a1, s1, pooled = small("a1", Cw), small("s1", Cw), small("pool", Cw)
@@ -291,24 +342,10 @@ class NAFNetWFIGate(nn.Module):
         hf_out = hf  # hf is dead after the proj GEMM: reuse its storage
         ops.conv_gemm(hidden, bp["ffn2_w"], hf_out, B=B, H=h, W=w, C_=2 * Cw, N=Cw, bias=bp["ffn2_b"], res=x1)
 
-        # ---------------- SpatialFrequencyFusionBlock (sffb.py:44-55) on ll
-        a3, s3 = small("a3", Cc), small("s3", Cc)
-        o, ln_ = bp["lnorm_ss"]
-        ops.ln2d_affine(ll, B, n, Cc, _EPS, bp["lnorm_g"], bp["lnorm_b"], cond_all[:, o:o + ln_], a3, s3, None, None, ws)
-        ms2 = buf("ms2", 3 * Cc, adt)
-        ops.dwconv_ms(ll, B, h, w, Cc, bp["ldw_t"], bp["ldw_b"], ms2, in_scale=a3, in_shift=s3)
-        spatial = buf("spat", Cc)
-        ops.conv_gemm(ms2, bp["lmerge_w"], spatial, B=B, H=h, W=w, C_=3 * Cc, N=Cc, bias=bp["lmerge_b"])
-        amp, ph = buf("amp", Cc), buf("ph", Cc)
-        fws = self._buf("fftws", 1, ops.fft_workspace_bytes(B, h, w, Cc) // 4, f32, dev)
-        ops.fft2_amp_phase(spatial, B, h, w, Cc, amp, ph, fws)
-        amp2, ph2 = buf("amp2", Cc), buf("ph2", Cc)
-        ops.conv_gemm(amp, bp["amp_w"], amp2, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["amp_b"])
-        ops.conv_gemm(ph, bp["ph_w"], ph2, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["ph_b"])
-        sf = amp  # amp is dead: reuse
-        ops.ifft2_polar_add(amp2, ph2, spatial, B, h, w, Cc, sf, fws)
-        lf = buf("lf", Cc)
-        ops.conv_gemm(sf, bp["reproj_w"], lf, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["reproj_b"])
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_event(sffb_done)
+        else:
+            lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl)
 
         # ---------------- CrossFrequencyConditioner (cfc.py:24-39)
         qvt, kvf = buf("qvt", 2 * Cc, adt), buf("kvf", 2 * Cc, adt)
