@@ -211,7 +211,7 @@ def main() -> None:
         dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
         roof = None
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_v5_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
+        tj = os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
         if os.path.exists(tj) and args.batch == 16 and args.size == 256 and args.precision == "bf16":
             with open(tj) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
