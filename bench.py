@@ -70,6 +70,9 @@ def main() -> None:
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--no-overlap", action="store_true",
                     help="encode and consumer back to back on one stream (default: encode of step k+1 on a second stream)")
+    ap.add_argument("--dual-replica", action="store_true",
+                    help="student: two forwards in flight on two buffer sets and streams (pipeline.DualReplicaRestorer; "
+                         "+1 %% throughput next to the other two overlaps, -2 %% on the dominant kernel: off by default)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="student: SFFB after WTB on one stream (default: SFFB on a second stream under WTB)")
     ap.add_argument("--rehearse", action="store_true",
@@ -113,9 +116,12 @@ def main() -> None:
 
     # a step = encode(clip view) -> consume(features); U/test.py:114-117: degra_features condition the net
     enc_in = clip_in
+    # --dual-replica: two forwards in flight on two activation-buffer sets / streams (pipeline.DualReplicaRestorer)
+    from underwater_image_restoration_amd.pipeline import DualReplicaRestorer
+    dual = DualReplicaRestorer(model) if args.dual_replica else None
 
     def consume(img_f, z_d):
-        return model(x, z_d, m)
+        return model(x, z_d, m) if dual is None else dual.submit(x, z_d, m)
 
     mp_per_step = args.batch * args.size * args.size / 1e6
     wl_name = None
@@ -162,7 +168,7 @@ def main() -> None:
         enc_in = cd
 
         def consume(img_f, z_d):  # noqa: F811
-            return model(xd, z_d, md)
+            return model(xd, z_d, md) if dual is None else dual.submit(xd, z_d, md)
         mp_per_step = Bd * 512 * 512 / 1e6
         wl_name = f"BASELINE configs[4]: 512x512 images, {Bd}/GPU per step, DA-CLIP z_d, {args.precision}"
 
@@ -239,6 +245,7 @@ def main() -> None:
                        "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
                        "encode_overlap": "none" if args.no_overlap else "next step's encode on a second HIP stream",
                        "branch_overlap": "none" if args.serial_branches else "SFFB on a second HIP stream under WTB",
+                       "forwards_in_flight": 2 if args.dual_replica else 1,
                        "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
                        "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -63,3 +63,27 @@ def test_student_branch_overlap_is_bit_identical():
         for o, alphas, logits in outs[1:]:
             assert torch.equal(o, outs[0][0]) and torch.equal(logits, outs[0][2])
             assert all(torch.equal(a, b) for a, b in zip(alphas, outs[0][1]))
+
+
+def test_dual_replica_restorer_is_bit_identical():
+    """Two forwards in flight on two buffer sets / streams: every batch's outputs equal the plain forward's, over two
+    passes (buffers reused), with the consumer waiting on the hand-over event only."""
+    from underwater_image_restoration_amd.pipeline import DualReplicaRestorer
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    model = NAFNetWFIGate(**MK, precision="bf16")
+    model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=5))
+    model = model.cuda().eval()
+    batches = [tuple(t.cuda() for t in synth_student_inputs(2, 128, 96, 512, 4, mask_hw=(7, 7), seed=80 + i)) for i in range(5)]
+    want = [tuple(model(*b)) for b in batches]
+    want = [(o.clone(), [a.clone() for a in al], lg.clone()) for o, al, lg in want]
+    torch.cuda.synchronize()
+    dual = DualReplicaRestorer(model)
+    assert dual.replicas[1] is not model and dual.replicas[1]._pack is model._pack      # shared packed weights
+    assert all(p is q for p, q in zip(model.parameters(), dual.replicas[1].parameters()))
+    for _ in range(2):
+        handles = [dual.submit(*b) for b in batches]
+        for h, (o, al, lg) in zip(handles, want):
+            got_o, got_al, got_lg = dual.wait(h)
+            assert torch.equal(got_o, o) and torch.equal(got_lg, lg)
+            assert all(torch.equal(a, b) for a, b in zip(got_al, al))
+    torch.cuda.synchronize()

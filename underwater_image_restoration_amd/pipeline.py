@@ -68,3 +68,61 @@ def restore_stream(encoder, restore: Callable, batches: Iterable[tuple]) -> Iter
             handle = pf.launch(nxt[1])
         yield restore(cur[0], z_d, cur[2])
         cur = nxt
+
+
+class DualReplicaRestorer:
+    """Two forwards of one student in flight: batches alternate between two activation-buffer sets (`model.replica()`,
+    shared weights) on two HIP streams, the second released when the first has passed its first WFI block, which keeps
+    the two a fraction of a forward apart.  The exp-bound attention launches of one batch then run next to the
+    HBM- and LDS-bound kernels of the other.  Measured at batch 16, 256x256: 54.5 -> 52.5 ms per batch on its own, but only
+    56.1 -> 55.5 ms next to the encode prefetch and the SFFB side stream, which already use most of the idle capacity,
+    and the level-0 attention launch slows by 2 % (its blocks fill the register file: foreign workgroups only get in
+    as its rounds retire).  Twice the activation memory.  An option for throughput-only loops; `bench.py` keeps it off.
+
+    `submit(x, z_d, masks)` enqueues a forward and returns `(outputs, done_event)`; make the consuming stream wait for
+    `done_event` (or call `wait(handle)`) before touching the outputs.  Outputs are bit-identical to `model(...)`."""
+
+    def __init__(self, model, stagger_after: int = 1) -> None:
+        self.replicas = [model, model.replica()]
+        dev = next(model.parameters()).device
+        self.device = dev
+        self.streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        self.stagger_after = stagger_after
+        self._turn = 0
+        self._mid = None          # event: the forward submitted last has enqueued `stagger_after` blocks
+
+    def submit(self, x: torch.Tensor, z_d: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        r = self._turn
+        self._turn ^= 1
+        model, st = self.replicas[r], self.streams[r]
+        st.wait_stream(torch.cuda.current_stream(self.device))   # inputs are ready
+        if self._mid is not None:
+            st.wait_event(self._mid)
+        mid = torch.cuda.Event()
+
+        def on_block(count: int) -> None:
+            if count == self.stagger_after:
+                mid.record(st)
+        model.on_block = on_block
+        try:
+            with torch.cuda.stream(st):
+                out = model(x, z_d, masks)
+                done = torch.cuda.Event()
+                done.record(st)
+        finally:
+            model.on_block = None
+        for t in (x, z_d, masks):
+            if t is not None:
+                t.record_stream(st)
+        self._mid = mid
+        return out, done
+
+    def wait(self, handle):
+        out, done = handle
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        restored, alphas, logits = out
+        for t in [restored, logits] + list(alphas):
+            if t is not None:
+                t.record_stream(cur)
+        return out

@@ -68,6 +68,7 @@ class NAFNetWFIGate(nn.Module):
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._streams: dict = {}            # device -> side stream of the SFFB branch
         self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
+        self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self) -> None:
@@ -91,6 +92,17 @@ class NAFNetWFIGate(nn.Module):
             self.precision = precision
             self._pack = None
         return self
+
+    def replica(self) -> "NAFNetWFIGate":
+        """A second set of activation buffers (and side stream) over THE SAME parameters and packed weights, so that two
+        forwards can be in flight on two streams (pipeline.DualReplicaRestorer).  A snapshot: re-create it after
+        load_state_dict / .to() / set_precision on the original."""
+        import copy
+        if self._pack is None:
+            self._pack = self._build_pack()
+        r = copy.copy(self)
+        r._bufs, r._streams, r.on_block = {}, {}, None
+        return r
 
     def _apply(self, fn, *a, **k):
         self._pack = None
@@ -437,6 +449,8 @@ class NAFNetWFIGate(nn.Module):
                 a = self._wfi_block(pk["blocks"][f"{prefix}.blocks.{bi}."], cur, B, Hl, Wl, cond_all, gate_in[lvl],
                                     dst, lvl, bt)
                 alphas.append(a.permute(0, 3, 1, 2))
+                if self.on_block is not None:
+                    self.on_block(len(alphas))     # pipeline.DualReplicaRestorer staggers its second stream on this
                 if taps is not None:
                     taps[f"{prefix}.blocks.{bi}"] = bt
                 cur = dst
