@@ -70,3 +70,19 @@ def compress(t, limit: int = 4096) -> np.ndarray:
         return a.astype(np.float32)
     step = -(-a.size // limit)
     return np.concatenate([a[::step], [a.mean(), np.abs(a).mean()]]).astype(np.float32)
+
+
+# Production-size cases (BASELINE configs[0] / configs[1] / configs[3] shapes): the packed-stream attention, the XCD
+# block remap, the bound-fallback split launch and the split-K thresholds only switch on at these sizes.  Outputs are
+# stored in full (fp32 roundings of the reference's fp64 run + its own fp32 run); no per-block taps.
+STUDENT_BIG_CASES = {
+    # exactly bench.py's image 0: production net, weights seed 0, inputs seed 1234, (10,7,7) masks, z_d ~ N(0,1)
+    "prod256": dict(base_channels=64, blocks_per_level=2, cond_dim=512, num_masks=10, num_deg=10, batch=1, H=256, W=256,
+                    mask_hw=(7, 7), wseed=0, xseed=1234, taps=["head"]),
+}
+
+UNET_BIG_CASES = {
+    # U/options/test.yml topology and width, one 256x256 sample, float time like t * sample_scale
+    "prod256": dict(nf=64, ch_mult=[1, 2, 4, 8], degra=True, image=True, batch=1, H=256, W=256, times=[37.0], wseed=8,
+                    xseed=35),
+}

@@ -24,8 +24,8 @@ sys.path.insert(0, "/root/reference")
 from underwater_image_restoration_amd.synth import (student_param_shapes, synth_state_dict,  # noqa: E402
                                                     synth_student_inputs)
 from underwater_image_restoration_amd.synth import daclip_vision_param_shapes, unet_param_shapes  # noqa: E402
-from tests.golden.cases import (DACLIP_CASES, STUDENT_CASES, UNET_CASES, compress, daclip_image,  # noqa: E402
-                                unet_inputs)
+from tests.golden.cases import (DACLIP_CASES, STUDENT_BIG_CASES, STUDENT_CASES, UNET_BIG_CASES, UNET_CASES,  # noqa: E402
+                                compress, daclip_image, unet_inputs)
 
 
 def student_case(name: str, cfg: dict) -> None:
@@ -72,9 +72,15 @@ def student_case(name: str, cfg: dict) -> None:
     model64 = model.double()
     with torch.no_grad():
         o64, a64, l64 = model64(x.double(), z.double(), masks=None if m is None else m.double())
-    store["out_f64"] = o64.numpy()
-    store["pre_clamp_f64"] = (taps.pop("head") + x.double()).numpy()
+    big = cfg["H"] * cfg["W"] >= 256 * 256   # production size: keep the file small (fp32 roundings of the fp64 run)
+    cast = (lambda a: a.astype(np.float32)) if big else (lambda a: a)
+    store["out_f64"] = cast(o64.numpy())
+    store["pre_clamp_f64"] = cast((taps.pop("head") + x.double()).numpy())
     store["alpha_last_f64"] = compress(a64[-1]).astype(np.float64)
+    if l64 is not None:
+        store["logits_f64"] = l64.numpy()
+    if big:
+        del store["pre_clamp"]
     np.savez_compressed(os.path.join(HERE, f"student_{name}.npz"), **store)
     print(name, "out range", float(out.min()), float(out.max()),
           "saturated frac", float(((out == 0) | (out == 1)).float().mean()))
@@ -232,7 +238,8 @@ def unet_case(name: str, cfg: dict) -> None:
         d = lambda z: None if z is None else z.double()  # noqa: E731
         for ti, t in enumerate(cfg["times"]):
             t64 = torch.tensor([float(t)], dtype=torch.float64)  # an int/float time would give an fp32 embedding
-            store[f"out{ti}_f64"] = m64(xt.double(), mu.double(), t64, text_context=d(text), image_context=d(image)).numpy()
+            o64 = m64(xt.double(), mu.double(), t64, text_context=d(text), image_context=d(image)).numpy()
+            store[f"out{ti}_f64"] = o64.astype(np.float32) if cfg["H"] * cfg["W"] >= 256 * 256 else o64
     np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **store)
     print("unet", name, "out |max|", float(np.abs(store["out0"]).max()), "fp32-vs-fp64", float(np.abs(store["out0"] - store["out0_f64"]).max()))
 
@@ -421,6 +428,12 @@ if __name__ == "__main__":
     if "student" in which:
         for name, cfg in STUDENT_CASES.items():
             student_case(name, cfg)
+    if "student_big" in which:      # not in the default set: minutes of CPU time and ~25 GB of RAM (fp64 CFC scores)
+        for name, cfg in STUDENT_BIG_CASES.items():
+            student_case(name, cfg)
+    if "unet_big" in which:
+        for name, cfg in UNET_BIG_CASES.items():
+            unet_case(name, cfg)
     if "sde" in which:
         sde_case()
     if "daclip" in which:

@@ -6,14 +6,14 @@ import os
 import numpy as np
 import torch
 
-from tests.golden.cases import STUDENT_CASES, compress
+from tests.golden.cases import STUDENT_BIG_CASES, STUDENT_CASES, compress
 from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def student_case_setup(name: str):
-    cfg = STUDENT_CASES[name]
+    cfg = STUDENT_CASES[name] if name in STUDENT_CASES else STUDENT_BIG_CASES[name]
     mk = dict(base_channels=cfg["base_channels"], num_levels=3, blocks_per_level=cfg["blocks_per_level"],
               cond_dim=cfg["cond_dim"], num_masks=cfg["num_masks"], num_degradation_types=cfg["num_deg"])
     sd = synth_state_dict(student_param_shapes(**mk), seed=cfg["wseed"])
@@ -51,4 +51,16 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     return 100.0 if mse < 1e-10 else 10.0 * float(np.log10(1.0 / mse))
 
 
-__all__ = ["student_case_setup", "oracle_tap_lookup", "max_abs", "psnr", "compress", "STUDENT_CASES"]
+def psnr_delta_at(build: torch.Tensor, ref: torch.Tensor, target_db: float = 30.0, seed: int = 4321) -> float:
+    """north_star's bf16 criterion "PSNR delta <= 0.05 dB", made falsifiable: a pseudo ground truth is derived from the
+    REFERENCE output by adding Gaussian noise at `target_db` (so the reference scores ~target_db against it, a typical
+    restoration quality); returned is |PSNR(ref, gt) - PSNR(build, gt)|.  With an error e independent of that noise
+    the delta is 10 log10(1 + mse_e / sigma^2): 0.05 dB at a 30 dB target <=> PSNR(build, ref) >= 49.4 dB, so the
+    criterion binds ~20 dB above the old random-target form."""
+    g = torch.Generator().manual_seed(seed)
+    sigma = 10.0 ** (-target_db / 20.0)
+    gt = ref.double().cpu() + sigma * torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    return abs(psnr(ref.cpu(), gt) - psnr(build.cpu(), gt))
+
+
+__all__ = ["psnr_delta_at", "student_case_setup", "oracle_tap_lookup", "max_abs", "psnr", "compress", "STUDENT_CASES"]

@@ -5,7 +5,7 @@ whole network, window-batching invariance of the halo tiling, batch independence
 import pytest
 import torch
 
-from tests.helpers import psnr
+from tests.helpers import psnr, psnr_delta_at
 from underwater_image_restoration_amd.synth import (daclip_vision_param_shapes, student_param_shapes, synth_state_dict,
                                                     synth_student_inputs, unet_param_shapes)
 
@@ -57,10 +57,9 @@ def test_configs1_batch16_256_properties(student):
         ref32 = model(x[:2].contiguous(), z[:2].contiguous(), m[:2].contiguous())[0]
     finally:
         model.set_precision("bf16")
-    target = torch.rand(ref32.shape, generator=torch.Generator().manual_seed(4321)).cuda()
-    delta = abs(psnr(ref32, target) - psnr(out[:2], target))
-    print(f"\n[configs1] PSNR(bf16, fp32) = {psnr(out[:2], ref32):.2f} dB, PSNR delta vs target = {delta:.4f} dB")
-    assert delta <= 0.05 and psnr(out[:2], ref32) > 40.0
+    delta = psnr_delta_at(out[:2], ref32)   # pseudo ground truth 30 dB away from the fp32 result (helpers.py)
+    print(f"\n[configs1] PSNR(bf16, fp32) = {psnr(out[:2], ref32):.2f} dB, PSNR delta at a 30 dB target = {delta:.4f} dB")
+    assert delta <= 0.05 and psnr(out[:2], ref32) >= 50.0   # element-wise vs the reference: tests/test_gpu_prodsize.py
 
 
 def test_configs2_1080p_tiling_invariants(student):

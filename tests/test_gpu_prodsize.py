@@ -1,0 +1,109 @@
+"""GPU: ELEMENT-WISE parity at BASELINE's production size -- one 256x256 image through the full-width student
+(configs[0] / configs[1] shapes) and one ConditionalUNet step at 256x256, nf = 64, [1, 2, 4, 8] (configs[3]) -- against
+outputs of the REFERENCE ITSELF at that size (tests/golden/{student,unet}_prod256.npz, written by
+tests/golden/make_golden.py student_big unet_big) and against the fp64 oracle run here.  At 256x256 the packed-stream
+attention (n = 16384), the XCD block remap, the bound-fallback split launch and the split-K thresholds are all live;
+the small golden cases never reach them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref as U
+from tests.golden.cases import UNET_BIG_CASES, unet_inputs
+from tests.helpers import GOLDEN, max_abs, psnr, psnr_delta_at, student_case_setup
+from underwater_image_restoration_amd.synth import synth_state_dict, unet_param_shapes
+
+pytestmark = pytest.mark.gpu
+FP32_TOL = 1e-4   # north_star: fp32 max abs error <= 1e-4 on [0,1] pixels
+
+
+@pytest.fixture(scope="module")
+def student_case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return student_case_setup("prod256")
+
+
+def _student(mk, sd, precision):
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    m = NAFNetWFIGate(**mk, precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+def test_student_256_fp32_elementwise(student_case):
+    cfg, mk, sd, x, z, m, gold = student_case
+    model = _student(mk, sd, "fp32")
+    taps = {}
+    out, alphas, logits = model(x.cuda(), z.cuda(), m.cuda(), taps=taps)
+    torch.cuda.synchronize()
+    out, pre = out.cpu().numpy(), taps["pre_clamp"].cpu().numpy()
+    e_out, e_pre = max_abs(out, gold["out_f64"]), max_abs(pre, gold["pre_clamp_f64"])
+    e_ref32 = max_abs(out, gold["out"])
+    e_log = max_abs(logits.cpu().numpy(), gold["logits_f64"])
+    print(f"\n[student prod256/fp32] vs reference fp64: out {e_out:.3e}  pre-clamp {e_pre:.3e}  logits {e_log:.3e};  "
+          f"vs reference fp32: {e_ref32:.3e}  (reference fp32 vs its own fp64: {max_abs(gold['out'], gold['out_f64']):.3e})")
+    assert e_out <= FP32_TOL and e_pre <= FP32_TOL
+    assert e_ref32 <= 2 * FP32_TOL        # the reference's fp32 run carries its own summation noise
+    assert e_log <= 1e-3
+    assert len(alphas) == 10
+    from tests.golden.cases import compress
+    for i, a in enumerate(alphas):
+        assert max_abs(compress(a), gold[f"alpha{i}"]) < 1e-3, i
+
+
+def test_student_256_bf16_psnr(student_case):
+    cfg, mk, sd, x, z, m, gold = student_case
+    ref = torch.from_numpy(gold["out_f64"])
+    model = _student(mk, sd, "bf16")
+    out = model(x.cuda(), z.cuda(), m.cuda())[0].cpu()
+    p, d = psnr(out, ref), psnr_delta_at(out, ref)
+    print(f"\n[student prod256/bf16] PSNR(build, reference fp64) = {p:.2f} dB, max abs {float((out.double() - ref).abs().max()):.3e}, "
+          f"PSNR delta at a 30 dB target = {d:.4f} dB")
+    assert p >= 50.0 and d <= 0.05
+
+
+def _unet(cfg, sd, precision):
+    from underwater_image_restoration_amd.unet import ConditionalUNet
+    m = ConditionalUNet(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"], precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def unet_case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cfg = UNET_BIG_CASES["prod256"]
+    sd = synth_state_dict(unet_param_shapes(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"]), seed=cfg["wseed"])
+    xt, mu, text, image = unet_inputs(cfg)
+    gold = np.load(os.path.join(GOLDEN, "unet_prod256.npz"))
+    U.FORCE_EPS = 1e-5   # the fp32 function at high precision (the reference's fp64 branch switches eps to 1e-3)
+    try:
+        with torch.no_grad():
+            ref64 = U.unet_forward({k: v.double() for k, v in sd.items()}, xt.double(), mu.double(),
+                                   torch.tensor([float(cfg["times"][0])], dtype=torch.float64), text.double(), image.double())
+    finally:
+        U.FORCE_EPS = None
+    return cfg, sd, (xt, mu, text, image), gold, ref64
+
+
+def test_unet_256_fp32_elementwise(unet_case):
+    cfg, sd, (xt, mu, text, image), gold, ref64 = unet_case
+    model = _unet(cfg, sd, "fp32")
+    out = model(xt.cuda(), mu.cuda(), cfg["times"][0], text_context=text.cuda(), image_context=image.cuda()).cpu().numpy()
+    e64, e32 = max_abs(out, ref64.numpy()), max_abs(out, gold["out0"])
+    print(f"\n[unet prod256/fp32] vs fp64 oracle (eps 1e-5): {e64:.3e}   vs the reference's fp32 output: {e32:.3e}  (|out|max "
+          f"{float(np.abs(gold['out0']).max()):.3f})")
+    assert e64 <= FP32_TOL and e32 <= 2 * FP32_TOL
+
+
+def test_unet_256_bf16(unet_case):
+    cfg, sd, (xt, mu, text, image), gold, ref64 = unet_case
+    model = _unet(cfg, sd, "bf16")
+    out = model(xt.cuda(), mu.cuda(), cfg["times"][0], text_context=text.cuda(), image_context=image.cuda()).cpu().double()
+    rel = float((out - ref64).norm() / ref64.norm())
+    print(f"\n[unet prod256/bf16] rel L2 {rel:.3e}  max abs {float((out - ref64).abs().max()):.3e}")
+    assert rel < 1e-2

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import student_ref as R
-from tests.helpers import STUDENT_CASES, compress, max_abs, oracle_tap_lookup, psnr, student_case_setup
+from tests.helpers import (STUDENT_CASES, compress, max_abs, oracle_tap_lookup, psnr, psnr_delta_at,
+                           student_case_setup)
 
 pytestmark = pytest.mark.gpu
 
@@ -71,8 +72,9 @@ def test_student_fp32_matches_oracle_and_golden(name):
 
 @pytest.mark.parametrize("name", ["full32", "rect"])
 def test_student_bf16_psnr(name):
-    """bf16 mode: PSNR(build, fp64 reference) must stay within 0.05 dB of the fp32 path's own PSNR w.r.t. a
-    clean target, and the direct PSNR(build_bf16, reference) is reported."""
+    """bf16 mode against the reference's own fp64 output: PSNR(build, ref) >= 60 dB at the golden sizes (measured
+    79-80 dB), and north_star's "PSNR delta <= 0.05 dB" against a pseudo ground truth DERIVED FROM the reference output
+    at 30 dB (helpers.psnr_delta_at: binds at PSNR(build, ref) ~ 49 dB; the former random-target delta could not fail)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     cfg, mk, sd, x, z, m, gold = student_case_setup(name)
@@ -80,15 +82,12 @@ def test_student_bf16_psnr(name):
     model = _model(mk, sd, "bf16")
     out, alphas, logits = model(x.cuda(), z.cuda(), None if m is None else m.cuda())
     out = out.cpu()
-    # pseudo ground truth: a smooth "clean" image; delta of PSNR against it between reference and bf16 build
-    g = torch.Generator().manual_seed(4321)
-    target = torch.rand(x.shape, generator=g)
-    d = abs(psnr(ref, target) - psnr(out, target))
+    d = psnr_delta_at(out, ref)
     p = psnr(out, ref)
     print(f"\n[{name}/bf16] PSNR(build,ref)={p:.2f} dB  max abs err={float((out.double()-ref).abs().max()):.3e}  "
-          f"PSNR delta vs target={d:.4f} dB")
+          f"PSNR delta at a 30 dB target={d:.4f} dB")
     assert d <= 0.05
-    assert p > 35.0
+    assert p >= 60.0
 
 
 def test_student_api_errors():

@@ -70,3 +70,16 @@ def test_attention_chunking_is_a_memory_device_only():
 def test_cond_required():
     with pytest.raises(ValueError):
         R.student_forward({}, torch.zeros(1, 3, 8, 8), None)
+
+
+def test_student_oracle_matches_reference_at_production_size():
+    """One 256x256 image through the full-width net (bench.py's CPU-baseline shape): the fp32 oracle against the
+    reference's own fp64 and fp32 outputs.  ~1 minute of CPU: the only production-size pin of the oracle."""
+    cfg, mk, sd, x, z, m, gold = student_case_setup("prod256")
+    taps = {}
+    with torch.no_grad():
+        out, alphas, logits = R.student_forward(sd, x, z, m, blocks_per_level=cfg["blocks_per_level"], taps=taps)
+    assert max_abs(out.numpy(), gold["out_f64"]) < TOL
+    assert max_abs(out.numpy(), gold["out"]) < 2 * TOL
+    assert max_abs(taps["pre_clamp"].numpy(), gold["pre_clamp_f64"]) < TOL
+    assert max_abs(logits.numpy(), gold["logits_f64"]) < 1e-4

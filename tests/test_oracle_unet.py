@@ -47,3 +47,21 @@ def test_force_eps_gives_high_precision_fp32_function(golden_dir):
     finally:
         U.FORCE_EPS = None
     assert max_abs(o64.numpy(), g["out0"]) < 2e-5
+
+
+def test_unet_oracle_matches_reference_at_production_size(golden_dir):
+    """One 256x256 step at nf = 64, [1, 2, 4, 8] (BASELINE configs[3] shape): the fp32 oracle against the reference's
+    own fp32 output, and the fp64 oracle (native eps 1e-3 branch) against the reference's fp64 output as stored (fp32
+    roundings, see make_golden.py)."""
+    from tests.golden.cases import UNET_BIG_CASES
+    cfg = UNET_BIG_CASES["prod256"]
+    sd = synth_state_dict(unet_param_shapes(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"]), seed=cfg["wseed"])
+    xt, mu, text, image = unet_inputs(cfg)
+    g = np.load(os.path.join(golden_dir, "unet_prod256.npz"))
+    t = cfg["times"][0]
+    with torch.no_grad():
+        out = U.unet_forward(sd, xt, mu, t, text, image)
+        o64 = U.unet_forward({k: v.double() for k, v in sd.items()}, xt.double(), mu.double(),
+                             torch.tensor([float(t)], dtype=torch.float64), text.double(), image.double())
+    assert max_abs(out.numpy(), g["out0"]) < 5e-5
+    assert max_abs(o64.numpy(), g["out0_f64"]) < 1e-6

@@ -228,6 +228,7 @@ class DaCLIPVision(nn.Module):
 
     # ------------------------------------------------------------------ reference-shaped API
     @torch.no_grad()
+    @ops.on_operand_device
     def encode_image(self, image: torch.Tensor, control: bool = False, normalize: bool = False):
         image = self._check_image(image)
         B = image.shape[0]
@@ -244,6 +245,9 @@ class DaCLIPVision(nn.Module):
 
     @torch.no_grad()
     def _tower_call(self, which: str, image: torch.Tensor, output_hiddens: bool, control: Optional[list]):
+        if image.is_cuda and image.device.index != torch.cuda.current_device():
+            with torch.cuda.device(image.device):
+                return self._tower_call(which, image, output_hiddens, control)
         image = self._check_image(image)
         B = image.shape[0]
         patches = self._patches(image)

@@ -39,7 +39,7 @@ def gamma_correction(image: torch.Tensor, gamma: float) -> torch.Tensor:
     """uiep_cwgr_ops.py:114-116."""
     x = _image(image, "gamma_correction")
     out = torch.empty_like(x)
-    _lib.check(_lib.load().uwir_gamma_correction(_p(x), _p(out), x.numel(), float(gamma), _stream()), "gamma_correction")
+    _lib.check(_lib.load().uwir_gamma_correction(_p(x), _p(out), x.numel(), float(gamma), _stream(x)), "gamma_correction")
     return out
 
 
@@ -49,7 +49,7 @@ def lf_hf_mix(low_freq: torch.Tensor, high_freq: torch.Tensor, alpha: float) -> 
     if lo.shape != hi.shape:
         raise RuntimeError(f"lf_hf_mix: shapes differ: {tuple(lo.shape)} vs {tuple(hi.shape)}")
     out = torch.empty_like(lo)
-    _lib.check(_lib.load().uwir_lf_hf_mix(_p(lo), _p(hi), float(alpha), _p(out), lo.numel(), _stream()), "lf_hf_mix")
+    _lib.check(_lib.load().uwir_lf_hf_mix(_p(lo), _p(hi), float(alpha), _p(out), lo.numel(), _stream(lo)), "lf_hf_mix")
     return out
 
 
@@ -62,7 +62,7 @@ def wavelet_denoise(image: torch.Tensor, threshold_scale: float = 1.0) -> torch.
     lib = _lib.load()
     ws = _workspace(x.device, int(lib.uwir_wavelet_denoise_workspace_bytes(c, h, w)))
     out = torch.empty_like(x)
-    _lib.check(lib.uwir_wavelet_denoise(_p(x), c, h, w, float(threshold_scale), _p(out), _p(ws), ws.numel(), _stream()),
+    _lib.check(lib.uwir_wavelet_denoise(_p(x), c, h, w, float(threshold_scale), _p(out), _p(ws), ws.numel(), _stream(x)),
                "wavelet_denoise")
     return out
 
@@ -82,7 +82,7 @@ def guided_filter(input_img: torch.Tensor, guidance: torch.Tensor, radius: int =
     lib = _lib.load()
     ws = _workspace(p.device, int(lib.uwir_guided_filter_workspace_bytes(h, w)))
     out = torch.empty(1, h, w, dtype=torch.float32, device=p.device)
-    _lib.check(lib.uwir_guided_filter(_p(p), _p(g), h, w, int(radius), float(eps), _p(out), _p(ws), ws.numel(), _stream()),
+    _lib.check(lib.uwir_guided_filter(_p(p), _p(g), h, w, int(radius), float(eps), _p(out), _p(ws), ws.numel(), _stream(p)),
                "guided_filter")
     return out
 
@@ -98,7 +98,7 @@ def multi_scale_retinex(image: torch.Tensor, sigmas: Sequence[float] = (15, 80, 
     ws = _workspace(x.device, int(lib.uwir_multi_scale_retinex_workspace_bytes(c, h, w)))
     sg = (ctypes.c_double * len(sigmas))(*[float(s) for s in sigmas])
     out = torch.empty_like(x)
-    _lib.check(lib.uwir_multi_scale_retinex(_p(x), c, h, w, sg, len(sigmas), _p(out), _p(ws), ws.numel(), _stream()),
+    _lib.check(lib.uwir_multi_scale_retinex(_p(x), c, h, w, sg, len(sigmas), _p(out), _p(ws), ws.numel(), _stream(x)),
                "multi_scale_retinex")
     return out
 
@@ -114,7 +114,7 @@ def state_features(image: torch.Tensor) -> Tuple[float, float, float, float]:
     lib = _lib.load()
     ws = _workspace(x.device, int(lib.uwir_enhance_state_workspace_bytes()))
     out = torch.empty(4, dtype=torch.float64, device=x.device)
-    _lib.check(lib.uwir_enhance_state(_p(x), c, h, w, _p(out), _p(ws), ws.numel(), _stream()), "enhance_state")
+    _lib.check(lib.uwir_enhance_state(_p(x), c, h, w, _p(out), _p(ws), ws.numel(), _stream(x)), "enhance_state")
     v = out.tolist()
     return v[0], v[1], v[2], v[3]
 

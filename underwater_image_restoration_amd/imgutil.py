@@ -31,7 +31,7 @@ def tensor2img_device(tensor: torch.Tensor, min_max=(0, 1)) -> torch.Tensor:
     if t.dim() == 3 and C_ != 3:
         raise IndexError("tensor2img: 3-D input must have 3 channels (the reference indexes channels [2, 1, 0])")
     _lib.check(_lib.load().uwir_tensor2img_u8(_p(t), C_, H, W, float(min_max[0]), float(min_max[1]), int(t.dim() == 3),
-                                              _p(out), _stream()), "tensor2img")
+                                              _p(out), _stream(out)), "tensor2img")
     return out
 
 
@@ -50,7 +50,7 @@ def calculate_psnr(img1, img2) -> float:
         raise ValueError("calculate_psnr: uint8 images of one shape expected")
     a, b = a.cuda().contiguous(), b.cuda().contiguous()
     acc = torch.empty(1, dtype=torch.int64, device=a.device)
-    _lib.check(_lib.load().uwir_sqdiff_u8(_p(a), _p(b), a.numel(), _p(acc), _stream()), "sqdiff_u8")
+    _lib.check(_lib.load().uwir_sqdiff_u8(_p(a), _p(b), a.numel(), _p(acc), _stream(a)), "sqdiff_u8")
     s = int(acc.item())
     if s == 0:
         return float("inf")

@@ -5,6 +5,7 @@ used purely as device-memory handles: 2-D ``[rows, ld]`` views (NHWC activations
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional
 
 import torch
@@ -13,8 +14,29 @@ from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, BF16, F32, GemmArgs  # noqa: F401
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t) -> int:
+    """HIP stream handle every launch of an op goes to: torch's current stream of the CURRENT device.  `t` is an
+    operand (tensor or device) of the op: the library launches in the current HIP device context, so an operand on
+    another GPU is an error here (it used to enqueue on the wrong GPU's stream silently).  The module-level entry
+    points (student / UNet / DA-CLIP / sampler forwards) make their input's device current themselves."""
+    s = torch.cuda.current_stream()
+    dev = t.device if isinstance(t, torch.Tensor) else t
+    if dev.type != "cuda" or (dev.index is not None and dev.index != s.device_index):
+        raise ValueError(f"operand on {dev} but the current HIP device is cuda:{s.device_index}: run under "
+                         f"torch.cuda.device(...) (the model-level forwards do)")
+    return s.cuda_stream
+
+
+def on_operand_device(fn):
+    """Decorator of the model-level entry points (methods whose first argument is a tensor): run with that tensor's
+    GPU as the current HIP device, so a model living on a non-current GPU launches in its own context / stream."""
+    @functools.wraps(fn)
+    def wrapper(self, x, *a, **k):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(self, x, *a, **k)
+        return fn(self, x, *a, **k)
+    return wrapper
 
 
 # Optional HIP-event timing of selected launches (bench.py's roofline leg).  Events are recorded on
@@ -62,13 +84,13 @@ def _ld(t: torch.Tensor) -> int:
 def dwt2(x: torch.Tensor, B: int, H: int, W: int, C: int, ll: torch.Tensor, hf: torch.Tensor) -> None:
     _f32(x, ll, hf)
     lib = _lib.load()
-    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _stream()), "dwt2")
+    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _stream(x)), "dwt2")
 
 
 def idwt2(ll: torch.Tensor, hf: torch.Tensor, B: int, h: int, w: int, C: int, out: torch.Tensor) -> None:
     _f32(ll, hf, out)
     lib = _lib.load()
-    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream()), "idwt2")
+    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream(ll)), "idwt2")
 
 
 def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
@@ -82,13 +104,13 @@ def ln2d_affine(x: torch.Tensor, B: int, n: int, C_: int, eps: float, gamma, bet
     ss_ld = 0 if scale_shift is None else _ld(scale_shift)
     _lib.check(lib.uwir_ln2d_affine(_p(x), _ld(x), B, n, C_, eps, _p(gamma), _p(beta), _p(scale_shift), ss_ld,
                                     _p(a_out), _p(s_out), _p(mean_out), _p(pooled_out), _p(workspace),
-                                    workspace.numel() * workspace.element_size(), _stream()), "ln2d_affine")
+                                    workspace.numel() * workspace.element_size(), _stream(x)), "ln2d_affine")
 
 
 def chan_attn_fold(a, s, w, out_scale, out_shift) -> None:
     _f32(a, s, w, out_scale, out_shift)
     lib = _lib.load()
-    _lib.check(lib.uwir_chan_attn_fold(_p(a), _p(s), _p(w), _p(out_scale), _p(out_shift), a.numel(), _stream()),
+    _lib.check(lib.uwir_chan_attn_fold(_p(a), _p(s), _p(w), _p(out_scale), _p(out_shift), a.numel(), _stream(a)),
                "chan_attn_fold")
 
 
@@ -99,7 +121,7 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], y: to
     O = W.shape[0]
     if W.shape[1] != I or not W.is_contiguous() or y.shape[0] != B or y.shape[1] != O:
         raise ValueError("linear: shape mismatch")
-    _lib.check(lib.uwir_linear(_p(x), _ld(x), B, I, _p(W), _p(bias), O, act, _p(y), _ld(y), _stream()), "linear")
+    _lib.check(lib.uwir_linear(_p(x), _ld(x), B, I, _p(W), _p(bias), O, act, _p(y), _ld(y), _stream(x)), "linear")
 
 
 _GEMM_WS = {}    # split-K scratch per (device, stream): calls that share one must be ordered on one stream
@@ -148,13 +170,13 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
     if _SPLITK and -(-(B * g.OH * g.OW) // 128) * -(-N // 128) < 128 and KH == 1 and g.a_dtype == BF16:
         need = int(lib.uwir_conv_gemm_workspace_bytes(C.byref(g)))   # few output tiles: lend the split-K scratch
         if need:
-            key = (A.device, _stream())
+            key = (A.device, _stream(A))
             ws = _GEMM_WS.get(key)
             if ws is None or ws.numel() * 4 < need:
                 ws = torch.zeros(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=A.device)  # counters start at 0
                 _GEMM_WS[key] = ws
             g.workspace, g.workspace_bytes = _p(ws), ws.numel() * 4
-    _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream()), "conv_gemm")
+    _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream(A)), "conv_gemm")
 
 
 def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, out: torch.Tensor, in_scale=None,
@@ -164,7 +186,7 @@ def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, ou
     b3, b5, b7 = biases
     _f32(w3, w5, w7, b3, b5, b7, in_scale, in_shift)
     _lib.check(lib.uwir_dwconv_ms(_p(x), _dt(x), _ld(x), B, H, W, C_, _p(in_scale), _p(in_shift), _p(w3), _p(w5),
-                                  _p(w7), _p(b3), _p(b5), _p(b7), _p(out), _dt(out), _ld(out), _stream()), "dwconv_ms")
+                                  _p(w7), _p(b3), _p(b5), _p(b7), _p(out), _dt(out), _ld(out), _stream(x)), "dwconv_ms")
 
 
 _ATTN_WS = {}
@@ -181,7 +203,7 @@ def _attn_workspace(dev, B: int, n: int, heads: int, hd: int, nv: int):
     lib = _lib.load()
     need = int(lib.uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) if _PACKED
                else lib.uwir_flash_attn_workspace_bytes(B, n, heads))
-    key = (dev, _stream())
+    key = (dev, _stream(dev))
     t = _ATTN_WS.get(key)
     if t is None or t.numel() * 4 < need:
         t = torch.empty(max(need // 4, 4096), dtype=torch.float32, device=dev)
@@ -207,7 +229,7 @@ def flash_attn(q, k, v1, v2, B: int, n: int, heads: int, hd: int, scale: float, 
     _lib.check(lib.uwir_flash_attn(_p(q), _ld(q), _p(k), _ld(k), _p(v1), _ld(v1), _p(v2),
                                    0 if v2 is None else _ld(v2), dt, B, n, heads, hd, scale, _p(o1), _ld(o1), _p(o2),
                                    0 if o2 is None else _ld(o2), _dt(o1), _p(ws), ws_bytes,
-                                   _stream()), "flash_attn")
+                                   _stream(q)), "flash_attn")
     if timed:
         _TIMING["events"].append((("flash_attn", B, n, heads, hd, 1 if v2 is None else 2, dt), ev0, ev1))
 
@@ -222,7 +244,7 @@ def fft2_amp_phase(x, B: int, H: int, W: int, C_: int, amp, phase, workspace) ->
     if _ld(amp) != _ld(phase):
         raise ValueError("fft2: amp / phase must share a row stride")
     _lib.check(lib.uwir_fft2_amp_phase(_p(x), _ld(x), B, H, W, C_, _p(amp), _p(phase), _ld(amp), _p(workspace),
-                                       workspace.numel() * workspace.element_size(), _stream()), "fft2_amp_phase")
+                                       workspace.numel() * workspace.element_size(), _stream(x)), "fft2_amp_phase")
 
 
 def ifft2_polar_add(amp, phase, addend, B: int, H: int, W: int, C_: int, out, workspace) -> None:
@@ -232,7 +254,7 @@ def ifft2_polar_add(amp, phase, addend, B: int, H: int, W: int, C_: int, out, wo
         raise ValueError("ifft2: amp / phase must share a row stride")
     _lib.check(lib.uwir_ifft2_polar_add(_p(amp), _p(phase), _ld(amp), _p(addend), _ld(addend), B, H, W, C_, _p(out),
                                         _ld(out), _p(workspace), workspace.numel() * workspace.element_size(),
-                                        _stream()), "ifft2_polar_add")
+                                        _stream(amp)), "ifft2_polar_add")
 
 
 def bilinear_nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, hd: int, wd: int) -> None:
@@ -241,7 +263,7 @@ def bilinear_nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, hd: int, wd: int
     if not src.is_contiguous() or src.dim() != 4:
         raise ValueError("bilinear: src must be a contiguous NCHW tensor")
     B, M, hs, ws = src.shape
-    _lib.check(lib.uwir_bilinear_nchw_to_nhwc(_p(src), B, M, hs, ws, _p(dst), _ld(dst), hd, wd, _stream()), "bilinear")
+    _lib.check(lib.uwir_bilinear_nchw_to_nhwc(_p(src), B, M, hs, ws, _p(dst), _ld(dst), hd, wd, _stream(src)), "bilinear")
 
 
 def stem_conv3x3(x_nchw: torch.Tensor, w, bias, out: torch.Tensor) -> None:
@@ -249,7 +271,7 @@ def stem_conv3x3(x_nchw: torch.Tensor, w, bias, out: torch.Tensor) -> None:
     lib = _lib.load()
     B, Cin, H, W = x_nchw.shape
     Cout = w.shape[-1]
-    _lib.check(lib.uwir_stem_conv3x3(_p(x_nchw), B, Cin, H, W, _p(w), _p(bias), Cout, _p(out), _ld(out), _stream()),
+    _lib.check(lib.uwir_stem_conv3x3(_p(x_nchw), B, Cin, H, W, _p(w), _p(bias), Cout, _p(out), _ld(out), _stream(x_nchw)),
                "stem_conv3x3")
 
 
@@ -258,7 +280,7 @@ def head_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, a_scale, a_s
     _f32(x, a_scale, a_shift, w, bias, residual_nchw, out_nchw, preclamp_nchw)
     lib = _lib.load()
     _lib.check(lib.uwir_head_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias), Cout,
-                                     _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream()), "head_conv3x3")
+                                     _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream(x)), "head_conv3x3")
 
 
 def sde_euler_step(x, mu, noise, eps, x_out, theta: float, sigma: float, sigma_bar: float, dt: float,
@@ -266,7 +288,7 @@ def sde_euler_step(x, mu, noise, eps, x_out, theta: float, sigma: float, sigma_b
     _f32(x, mu, noise, eps, x_out)
     lib = _lib.load()
     _lib.check(lib.uwir_sde_euler_step(_p(x), _p(mu), _p(noise), _p(eps), _p(x_out), x.numel(), theta, sigma,
-                                       sigma_bar, dt, score_weight, _stream()), "sde_euler_step")
+                                       sigma_bar, dt, score_weight, _stream(x)), "sde_euler_step")
 
 
 def sde_posterior_step(x, mu, noise, eps, x_out, sigma_bar: float, expA: float, term1: float, term2: float,
@@ -274,7 +296,7 @@ def sde_posterior_step(x, mu, noise, eps, x_out, sigma_bar: float, expA: float, 
     _f32(x, mu, noise, eps, x_out)
     lib = _lib.load()
     _lib.check(lib.uwir_sde_posterior_step(_p(x), _p(mu), _p(noise), _p(eps), _p(x_out), x.numel(), sigma_bar, expA,
-                                           term1, term2, std, _stream()), "sde_posterior_step")
+                                           term1, term2, std, _stream(x)), "sde_posterior_step")
 
 
 def gemm(A: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor, **kw) -> None:
@@ -294,7 +316,7 @@ def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, ad
         raise ValueError("ln_rows: add table must be [add_period, C]")
     _lib.check(lib.uwir_ln_rows(_p(x), _ld(x), M, C_, _p(add), add_period, 0 if add is None else _ld(add), _p(gamma),
                                 _p(beta), eps, _p(res), 0 if res is None else _ld(res), _p(y), _dt(y), _ld(y),
-                                _stream()), "ln_rows")
+                                _stream(x)), "ln_rows")
 
 
 def patchify(img: torch.Tensor, P: int, out: torch.Tensor) -> None:
@@ -303,7 +325,7 @@ def patchify(img: torch.Tensor, P: int, out: torch.Tensor) -> None:
     if img.dim() != 4 or not img.is_contiguous():
         raise ValueError("patchify: image must be a contiguous NCHW tensor")
     B, Cin, H, W = img.shape
-    _lib.check(lib.uwir_patchify(_p(img), B, Cin, H, W, P, _p(out), _dt(out), _ld(out), _stream()), "patchify")
+    _lib.check(lib.uwir_patchify(_p(img), B, Cin, H, W, P, _p(out), _dt(out), _ld(out), _stream(img)), "patchify")
 
 
 def add_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
@@ -312,7 +334,7 @@ def add_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
     M, C_ = a.shape
     if b.shape != a.shape or out.shape != a.shape:
         raise ValueError("add_rows: shape mismatch")
-    _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C_, _stream()), "add_rows")
+    _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C_, _stream(a)), "add_rows")
 
 
 def unet_input(xt: torch.Tensor, cond: torch.Tensor, Hp: int, Wp: int, out: torch.Tensor) -> None:
@@ -324,7 +346,7 @@ def unet_input(xt: torch.Tensor, cond: torch.Tensor, Hp: int, Wp: int, out: torc
     B, Cin, H, W = xt.shape
     if not out.is_contiguous() or out.shape[0] != B * Hp * Wp:
         raise ValueError("unet_input: bad output buffer")
-    _lib.check(lib.uwir_unet_input(_p(xt), _p(cond), B, Cin, H, W, Hp, Wp, out.shape[1], _p(out), _stream()), "unet_input")
+    _lib.check(lib.uwir_unet_input(_p(xt), _p(cond), B, Cin, H, W, Hp, Wp, out.shape[1], _p(out), _stream(xt)), "unet_input")
 
 
 def groupnorm_affine(x: torch.Tensor, B: int, n: int, C_: int, groups: int, eps: float, gamma, beta, a_out, s_out,
@@ -332,7 +354,7 @@ def groupnorm_affine(x: torch.Tensor, B: int, n: int, C_: int, groups: int, eps:
     _f32(x, gamma, beta, a_out, s_out)
     lib = _lib.load()
     _lib.check(lib.uwir_groupnorm_affine(_p(x), _ld(x), B, n, C_, groups, eps, _p(gamma), _p(beta), _p(a_out), _p(s_out),
-                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream()),
+                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream(x)),
                "groupnorm_affine")
 
 
@@ -343,7 +365,7 @@ def linattn_workspace_bytes(B: int, n: int, heads: int) -> int:
 def linear_attention(qkv: torch.Tensor, B: int, n: int, heads: int, out: torch.Tensor, workspace: torch.Tensor) -> None:
     lib = _lib.load()
     _lib.check(lib.uwir_linear_attention(_p(qkv), _dt(qkv), _ld(qkv), B, n, heads, _p(out), _dt(out), _ld(out),
-                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream()),
+                                         _p(workspace), workspace.numel() * workspace.element_size(), _stream(qkv)),
                "linear_attention")
 
 
@@ -352,21 +374,21 @@ def geglu(h: torch.Tensor, out: torch.Tensor) -> None:
     M, F2 = h.shape
     if _dt(h) != _dt(out) or out.shape[0] != M or out.shape[1] * 2 != F2:
         raise ValueError("geglu: h must be [M, 2F] and out [M, F] of one dtype")
-    _lib.check(lib.uwir_geglu(_p(h), _dt(h), _ld(h), M, F2 // 2, _p(out), _ld(out), _stream()), "geglu")
+    _lib.check(lib.uwir_geglu(_p(h), _dt(h), _ld(h), M, F2 // 2, _p(out), _ld(out), _stream(h)), "geglu")
 
 
 def softmax_rows(x: torch.Tensor, mul, y: torch.Tensor) -> None:
     _f32(x, mul, y)
     lib = _lib.load()
     B, C_ = x.shape
-    _lib.check(lib.uwir_softmax_rows(_p(x), _ld(x), B, C_, _p(mul), _p(y), _ld(y), _stream()), "softmax_rows")
+    _lib.check(lib.uwir_softmax_rows(_p(x), _ld(x), B, C_, _p(mul), _p(y), _ld(y), _stream(x)), "softmax_rows")
 
 
 def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cout: int, out_nchw: torch.Tensor) -> None:
     _f32(x, w, bias, out_nchw)
     lib = _lib.load()
     Ho, Wo = out_nchw.shape[2], out_nchw.shape[3]
-    _lib.check(lib.uwir_tail_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream()),
+    _lib.check(lib.uwir_tail_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream(x)),
                "tail_conv3x3")
 
 
@@ -374,7 +396,7 @@ def affine_cast(x: torch.Tensor, B: int, n: int, C_: int, a, s, out: torch.Tenso
     """out[m, c] = a[b, c] * x[m, c] + s[b, c] (b = m // n); x fp32, out fp32 / bf16."""
     _f32(x, a, s)
     lib = _lib.load()
-    _lib.check(lib.uwir_affine_cast(_p(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream()),
+    _lib.check(lib.uwir_affine_cast(_p(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream(x)),
                "affine_cast")
 
 
@@ -387,6 +409,6 @@ def image_metrics(x: torch.Tensor, y: torch.Tensor, c1: float = 0.01 ** 2, c2: f
     B, C_, H, W = x.shape
     ws = torch.empty(int(lib.uwir_image_metrics_workspace_bytes(B, C_, H, W)) // 8, dtype=torch.float64, device=x.device)
     out = torch.empty(B, 3, dtype=torch.float32, device=x.device)
-    _lib.check(lib.uwir_image_metrics(_p(x), _p(y), B, C_, H, W, c1, c2, _p(out), _p(ws), ws.numel() * 8, _stream()),
+    _lib.check(lib.uwir_image_metrics(_p(x), _p(y), B, C_, H, W, c1, c2, _p(out), _p(ws), ws.numel() * 8, _stream(x)),
                "image_metrics")
     return out

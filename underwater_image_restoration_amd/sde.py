@@ -152,6 +152,7 @@ class IRSDE:
             mu = torch.full_like(x, float(mu))
         return mu.expand_as(x)
 
+    @ops.on_operand_device
     def reverse_sde_step_from_noise(self, x, noise_pred, t: int, eps=None, score_weight: float = 1.0, out=None):
         x, noise_pred, mu = self._prep(x, noise_pred, self._mu_like(x))
         if eps is None:
@@ -167,6 +168,7 @@ class IRSDE:
                            float(self.dt), score_weight)
         return out
 
+    @ops.on_operand_device
     def reverse_posterior_step(self, xt, noise, t: int, eps=None, out=None):
         xt, noise, mu = self._prep(xt, noise, self._mu_like(xt))
         if eps is None:

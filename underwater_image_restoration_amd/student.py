@@ -391,6 +391,7 @@ class NAFNetWFIGate(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @ops.on_operand_device
     def forward(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None, taps: Optional[dict] = None
                 ) -> Tuple[torch.Tensor, List[torch.Tensor], Optional[torch.Tensor]]:
         if cond is None:

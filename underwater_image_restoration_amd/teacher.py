@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import _p, _stream
+from .ops import _p, _stream, on_operand_device
 
 
 @dataclass
@@ -84,6 +84,7 @@ class DifferentiableGuidedCRF(nn.Module):
         a.crf_sigma, a.crf_edge_weight = float(self.spatial_sigma), float(self.edge_weight)
 
     @torch.no_grad()
+    @on_operand_device
     def forward(self, probs: torch.Tensor, image: torch.Tensor, confidence: Optional[torch.Tensor] = None) -> torch.Tensor:
         _need_cuda(probs, image, confidence)
         if probs.dim() != 4 or image.dim() != 4 or image.shape[0] != probs.shape[0]:
@@ -99,7 +100,7 @@ class DifferentiableGuidedCRF(nn.Module):
         a.probs = _p(out)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel() * 4
         self._fill(a, img)
-        _lib.check(_lib.load().uwir_guided_crf(C.byref(a), _p(pin), _p(conf), _stream()), "guided_crf")
+        _lib.check(_lib.load().uwir_guided_crf(C.byref(a), _p(pin), _p(conf), _stream(pin)), "guided_crf")
         return out.to(probs.dtype)
 
 
@@ -138,6 +139,7 @@ class MaskHead(nn.Module):
         raise ValueError("Unsupported token shape for MaskHead input.")
 
     @torch.no_grad()
+    @on_operand_device
     def forward(self, image_tokens: torch.Tensor, text_embeddings: torch.Tensor,
                 grid_size: Optional[Tuple[int, int]] = None, thresholds: Optional[Iterable[float]] = None,
                 temperature: Optional[float] = None, alpha: Optional[float] = None,
@@ -183,7 +185,7 @@ class MaskHead(nn.Module):
         a.avg_intensity, a.global_prob, a.confidence, a.logits = (_p(stats[i]) for i in range(4))
         a.code, a.confidence_scale = _p(code), _p(cscale)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel() * 4
-        _lib.check(_lib.load().uwir_teacher_heads(C.byref(a), _stream()), "teacher_heads")
+        _lib.check(_lib.load().uwir_teacher_heads(C.byref(a), _stream(ws)), "teacher_heads")
         return MaskHeadOutput(scores=maps[0], probs=maps[1], masks=maps[2], intensity=maps[3], avg_intensity=stats[0],
                               global_prob=stats[1], confidence=stats[2], raw_probs=maps[4], used_crf=used_crf,
                               _logits=stats[3], _code=code, _confidence_scale=cscale)

@@ -65,6 +65,7 @@ class TiledRestorer:
         return plan_tiles(H, W, self.tile, self.halo)
 
     @torch.no_grad()
+    @ops.on_operand_device
     def frame_masks(self, masks: Optional[torch.Tensor], H: int, W: int) -> Optional[torch.Tensor]:
         """(B,M,hm,wm) -> (B,M,H,W): F.interpolate(bilinear, align_corners=False) on the device kernel."""
         if masks is None:
@@ -101,6 +102,7 @@ class TiledRestorer:
         return out
 
     @torch.no_grad()
+    @ops.on_operand_device
     def __call__(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x.dim() != 4:
             raise ValueError("Input must be (B, C, H, W).")

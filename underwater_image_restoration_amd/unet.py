@@ -277,6 +277,7 @@ class ConditionalUNet(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @ops.on_operand_device
     def forward(self, xt: torch.Tensor, cond: torch.Tensor, time, text_context: Optional[torch.Tensor] = None,
                 image_context: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
         if not xt.is_cuda:
