@@ -60,6 +60,20 @@ int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, co
                      const float* scale_shift, int ss_ld, float* a_out, float* s_out, float* mean_out,
                      float* pooled_out, void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
+/* ---- allocation-free variant of uwir_ln2d_affine.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory or hand over a workspace -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same arguments and bit-identical results, minus the workspace: the fp64 partial
+ * sums go to a built-in static device array of UWIR_LN2D_NOALLOC_SCRATCH_BYTES per GPU (held until the process
+ * ends).  Shapes whose partials exceed it (uwir_ln2d_workspace_bytes(B,n,C) > uwir_ln2d_noalloc_max_bytes()) are
+ * rejected with UWIR_EINVAL.  Calls no hipMalloc / hipFree / allocating routine.  All calls on one GPU share that GPU's
+ * array: calls that may overlap on one GPU (two streams, two threads) race -- order them, or use uwir_ln2d_affine
+ * with separate workspaces.  The device is the one current at the call (the stream must belong to it). */
+#define UWIR_LN2D_NOALLOC_SCRATCH_BYTES (16u << 20)
+size_t uwir_ln2d_noalloc_max_bytes(void);
+int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+                             const float* beta, const float* scale_shift, int ss_ld, float* a_out, float* s_out,
+                             float* mean_out, float* pooled_out, uwir_stream_t stream);
+
 /* ---- materialised form of the same norm (S/utils.py:18-36): out[m,c] = a[b,c]*x[m,c] + s[b,c], b = m / n, out fp32
  * or bf16.  For consumers that are better fed a ready bf16 operand (LDS-DMA GEMM path) than normalise-on-load. */
 int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, const float* a, const float* s, void* out,

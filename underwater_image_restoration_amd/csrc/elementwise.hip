@@ -2,6 +2,7 @@
 // bilinear mask resize, stem/head 3x3 convs, fused IR-SDE steps.  All NHWC, fp32, float4 lanes.
 #include "common.h"
 #include <string.h>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -15,7 +16,7 @@ int uwir_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* uwir_last_error(void) { return g_err; }
-extern "C" int uwir_version(void) { return 100; }
+extern "C" int uwir_version(void) { return 200; }
 
 // ------------------------------------------------------------------------------------------
 // Haar DWT / IDWT.  The reference tap is fl32(2^-0.5)^2 (S/dwt_fft.py:10-21), not 0.5.
@@ -261,6 +262,53 @@ extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, fl
                        pooled_out, B);
     UWIR_LAUNCH_CHECK("ln_finalize");
     return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Allocation-free variant (include/uwir.h: uwir_ln2d_affine_noalloc).  Same two kernels; the fp64 partial sums live in
+// a file-scope device array instead of a caller workspace.  Every GPU holds its own copy of the array at its own
+// address: the address is looked up once per device (with that device current) and only that pointer is ever handed
+// to kernels -- the array's NAME is a host-side stand-in, not a device address.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char ln2d_scratch[UWIR_LN2D_NOALLOC_SCRATCH_BYTES];
+
+#define UWIR_MAX_DEVICES 64
+static void* g_ln2d_scratch_ptr[UWIR_MAX_DEVICES];   // per device; written once under the mutex, then read-only
+static std::mutex g_ln2d_scratch_mu;
+
+static int ln2d_scratch_for_current_device(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return uwir_set_error(UWIR_ELAUNCH, "ln2d_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= UWIR_MAX_DEVICES) return uwir_set_error(UWIR_EUNSUPPORTED, "ln2d_noalloc: device index %d", dev);
+    std::lock_guard<std::mutex> lock(g_ln2d_scratch_mu);
+    if (!g_ln2d_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(ln2d_scratch));   // this device's copy (device `dev` is current)
+        if (e != hipSuccess || !ptr)
+            return uwir_set_error(UWIR_ELAUNCH, "ln2d_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_ln2d_scratch_ptr[dev] = ptr;
+    }
+    *out = g_ln2d_scratch_ptr[dev];
+    return UWIR_OK;
+}
+
+extern "C" size_t uwir_ln2d_noalloc_max_bytes(void) { return UWIR_LN2D_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+                                        const float* beta, const float* scale_shift, int ss_ld, float* a_out,
+                                        float* s_out, float* mean_out, float* pooled_out, uwir_stream_t stream) {
+    UWIR_CHECK(B > 0 && n > 0 && C > 0, "ln2d_noalloc: bad shape B=%d n=%d C=%d", B, n, C);
+    const size_t need = uwir_ln2d_workspace_bytes(B, n, C);
+    UWIR_CHECK(need <= (size_t)UWIR_LN2D_NOALLOC_SCRATCH_BYTES,
+               "ln2d_noalloc: B=%d n=%d C=%d needs %zu bytes of partial sums, the built-in scratch holds %zu "
+               "(use uwir_ln2d_affine with a caller workspace)", B, n, C, need, (size_t)UWIR_LN2D_NOALLOC_SCRATCH_BYTES);
+    void* ptr = nullptr;
+    int rc = ln2d_scratch_for_current_device(&ptr);
+    if (rc != UWIR_OK) return rc;
+    // every partial that ln_finalize reads is written by ln_partial of THIS call first: nothing needs clearing
+    return uwir_ln2d_affine(x, ldx, B, n, C, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out, pooled_out, ptr,
+                            need, stream);
 }
 
 // ------------------------------------------------------------------------------------------
