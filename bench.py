@@ -7,8 +7,11 @@ A "step" = one pass of the hot path over one batch of synthetic images already r
 DA-CLIP ViT-B/32 encode_image(control=True) on the (B,3,224,224) CLIP view -> z_d = degra_features (B,512)
 -> student NAFNetWFIGate forward on the (B,3,256,256) images conditioned on z_d and (B,10,7,7) masks.
 N=1 workload = BASELINE.json configs[1]: batch 16 at 256x256, bf16 MFMA compute.
-N>1: images are independent, so every rank runs its own batch (weak scaling, no data-path collective);
-RCCL is used only for the barrier and the MAX-over-ranks of the step time.
+N>1: one process per GPU.  Started bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process
+only spawns the N ranks (before touching the GPU) and relays rank 0's line; under torch.distributed.run it IS a rank.
+Images are independent, so every rank runs its own batch (weak scaling, no data-path collective); RCCL is used only for
+the barrier and the MAX-over-ranks of the step time.  `--workload dataset4096` is the strong-scaling leg (configs[4]):
+a fixed set of 512x512 images split over the ranks by shard.shard_range, metrics all-reduced.
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
@@ -25,9 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
-
-
+HBM_PEAK_GBS = 8000.0
 DACLIP_GF_PER_IMAGE = 18.2e9  # both ViT-B/32 towers, SURVEY.md section 6
+MK = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
 
 
 def student_flops(batch: int, size: int) -> float:
@@ -36,26 +39,122 @@ def student_flops(batch: int, size: int) -> float:
     return batch * (462e9 * r * r + 1401e9 * r ** 4 + DACLIP_GF_PER_IMAGE)
 
 
-def cpu_baseline(mk, sd, clip_sd, size: int, threads: int):
-    """The oracle (CPU restatement of the reference: oracle/daclip_ref.py + oracle/student_ref.py) timed on the
-    host cores on a bounded sample of the same workload (one image)."""
+def cpu_baseline(sd, clip_sd, x1, m1, clip1, threads: int):
+    """The oracle (CPU restatement of the reference: oracle/daclip_ref.py + oracle/student_ref.py) timed on the host
+    cores on a bounded sample of the same workload: image 0 of the timed batch.  -> (record, restored image 0)."""
     from oracle import daclip_ref as DR
     from oracle import student_ref as R
-    from underwater_image_restoration_amd.synth import synth_student_inputs
     torch.set_num_threads(threads)
-    x, _, m = synth_student_inputs(1, size, size, mk["cond_dim"], mk["num_masks"], mask_hw=(7, 7), seed=1234)
-    clip_in = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    size = x1.shape[-1]
     t0 = time.time()
     with torch.no_grad():
-        _, z = DR.encode_image(clip_sd, clip_in, 12, control=True)
-        R.student_forward(sd, x, z, m, blocks_per_level=mk["blocks_per_level"])
+        _, z = DR.encode_image(clip_sd, clip1, 12, control=True)
+        out, _, _ = R.student_forward(sd, x1, z, m1, blocks_per_level=MK["blocks_per_level"])
     dt = time.time() - t0
-    return {"value": round(size * size / 1e6 / dt, 6), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": f"1 image {size}x{size} fp32: DA-CLIP encode + student forward "
-                      f"(oracle/daclip_ref.py + oracle/student_ref.py, torch CPU, {threads} threads), {dt:.1f} s"}
+    rec = {"value": round(size * size / 1e6 / dt, 6), "unit": "MP/s", "cores": threads, "kind": "port",
+           "sample": f"image 0 of the timed batch, {size}x{size} fp32: DA-CLIP encode + student forward "
+                     f"(oracle/daclip_ref.py + oracle/student_ref.py, torch CPU, {threads} threads), {dt:.1f} s"}
+    return rec, out
 
 
-def main() -> None:
+# ----------------------------------------------------------------------------------------------------------------------
+# per-kernel-class roofline list: algorithmic work of one launcher call (SURVEY.md 8(d) formulas), from its arguments
+# ----------------------------------------------------------------------------------------------------------------------
+def _esz(t) -> int:
+    return t.element_size()
+
+
+def _op_work(name: str, a: tuple, k: dict):
+    """-> (class label, 'flop' | 'byte', amount) or None for launchers that are not listed."""
+    if name == "conv_gemm":
+        A, Wt, out = a[0], a[1], a[2]
+        B, H, W, C, N = k["B"], k["H"], k["W"], k["C_"], k["N"]
+        KH, st, ups = k.get("KH", 1), k.get("stride", 1), k.get("ups", 0)
+        pad = k.get("pad", 0)
+        OH, OW = ((H << ups) + 2 * pad - KH) // st + 1, ((W << ups) + 2 * pad - k.get("KW", 1)) // st + 1
+        M, K = B * OH * OW, KH * k.get("KW", 1) * C
+        bf = Wt.dtype == torch.bfloat16
+        if KH == 3 and st == 1 and bf:
+            cls = f"conv3x3 (halo tiles) N={N}" if N <= 64 else "conv3x3 (halo tiles) N>=128"
+        elif KH == 1 and K >= 1728 and bf:
+            cls = "1x1 GEMM K>=1728 (dw_merge)"
+        elif KH == 1 and bf:
+            cls = "1x1 GEMM K<1728 (bf16)"
+        else:
+            return None
+        return cls, "flop", 2.0 * M * N * K
+    if name == "flash_attn":
+        q, v2 = a[0], a[3]
+        B, n, heads, hd = a[4], a[5], a[6], a[7]
+        if q.dtype != torch.bfloat16:
+            return None
+        nv = 1 if v2 is None else 2
+        return f"attention {nv}V hd={hd} n={n} (incl. pack pre-pass)", "flop", (4.0 if nv == 1 else 6.0) * B * heads * float(n) ** 2 * hd
+    if name == "dwconv_ms":
+        x, B, H, W, C, out = a[0], a[1], a[2], a[3], a[4], a[7]
+        return "depthwise 3x3+5x5+7x7", "byte", float(B * H * W * C) * (_esz(x) + 3 * _esz(out))
+    if name == "ln2d_affine":
+        x, B, n, C = a[0], a[1], a[2], a[3]
+        return "LayerNorm2d statistics", "byte", float(B * n * C) * 4
+    if name == "dwt2":
+        B, H, W, C = a[1], a[2], a[3], a[4]
+        return "Haar DWT", "byte", 2.0 * 4 * B * H * W * C
+    if name == "idwt2":
+        B, h, w, C = a[2], a[3], a[4], a[5]
+        return "Haar IDWT", "byte", 2.0 * 4 * B * 4 * h * w * C
+    if name == "fft2_amp_phase":
+        B, H, W, C = a[1], a[2], a[3], a[4]
+        return "fft2 -> amp, phase", "byte", 3.0 * 4 * B * H * W * C
+    if name == "ifft2_polar_add":
+        B, H, W, C = a[3], a[4], a[5], a[6]
+        return "ifft2(amp, phase) + addend", "byte", 4.0 * 4 * B * H * W * C
+    if name == "affine_cast":
+        x, B, n, C, out = a[0], a[1], a[2], a[3], a[6]
+        return "affine_cast (norm materialised)", "byte", float(B * n * C) * (4 + _esz(out))
+    if name in ("sde_posterior_step", "sde_euler_step"):
+        return "fused SDE step", "byte", 20.0 * a[0].numel()
+    if name == "linear_attention":
+        qkv, B, n, heads, out = a[0], a[1], a[2], a[3], a[4]
+        # k read twice (max, then exp-sum with v), v once, q once, out once: module_util.py:170-183
+        return "LinearAttention core", "byte", float(B * n * heads * 32) * (4 * _esz(qkv) + _esz(out))
+    if name == "ln_rows":
+        x, y = a[0], a[3]
+        return "channel LayerNorm rows", "byte", float(x.shape[0] * x.shape[1]) * (4 + _esz(y) + (4 if k.get("res") is not None else 0))
+    if name == "head_conv3x3":
+        B, H, W, Cin = a[1], a[2], a[3], a[4]
+        return "final norm + head 3x3 + clamp", "byte", float(B * H * W) * (4 * Cin + 3 * 4 * 2)
+    if name == "stem_conv3x3":
+        x, out = a[0], a[3]
+        return "stem 3x3", "byte", float(x.numel() * 4 + out.shape[0] * 64 * 4)
+    return None
+
+
+def census_table(rows, precision: str):
+    """rows: ops.collect_op_census() -> list of {kernel class, bound, achieved, peak, unit, frac, calls, ms_per_step}."""
+    agg = {}
+    for name, a, k, ms in rows:
+        w = _op_work(name, a, k)
+        if w is None:
+            continue
+        cls, kind, amount = w
+        e = agg.setdefault(cls, {"kind": kind, "amount": 0.0, "ms": 0.0, "calls": 0})
+        e["amount"] += amount
+        e["ms"] += ms
+        e["calls"] += 1
+    out = []
+    for cls, e in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        if e["ms"] <= 0:
+            continue
+        if e["kind"] == "flop":
+            ach, peak, unit, bound = e["amount"] / (e["ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS[precision], "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = e["amount"] / (e["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        out.append({"class": cls, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "calls": e["calls"], "ms_total": round(e["ms"], 3)})
+    return out
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -63,11 +162,18 @@ def main() -> None:
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="student", choices=["student", "tiled1080", "sde", "dataset512"],
-                    help="student = BASELINE configs[1] (the headline line); the others are configs[2], [3], [4]")
+    ap.add_argument("--workload", default="student", choices=["student", "tiled1080", "sde", "dataset512", "dataset4096"],
+                    help="student = BASELINE configs[1] (the headline line); the others are configs[2], [3], [4] "
+                         "(dataset512: 4 images per rank and step, weak; dataset4096: --images 512x512 images split over "
+                         "the ranks, strong)")
+    ap.add_argument("--images", type=int, default=4096, help="dataset4096: total images (all ranks together)")
+    ap.add_argument("--dataset-size", type=int, default=512, help="dataset4096 / dataset512: image edge")
+    ap.add_argument("--dataset-batch", type=int, default=4, help="dataset4096 / dataset512: images per forward")
+    ap.add_argument("--gather", action="store_true", help="dataset4096: also gather the restored images to rank 0")
     ap.add_argument("--sde-steps", type=int, default=100)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
-    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--census", default="auto", choices=["auto", "skip"],
+                    help="one extra untimed single-stream pass with HIP events around every launcher -> roofline.kernels")
     ap.add_argument("--no-overlap", action="store_true",
                     help="encode and consumer back to back on one stream (default: encode of step k+1 on a second stream)")
     ap.add_argument("--dual-replica", action="store_true",
@@ -75,188 +181,375 @@ def main() -> None:
                          "+1 %% throughput next to the other two overlaps, -2 %% on the dominant kernel: off by default)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="student: SFFB after WTB on one stream (default: SFFB on a second stream under WTB)")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the ranks rendezvous over gloo "
-                         "(checks the barrier / max-over-ranks / rank-0 reporting logic; the number is not a result)")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse", nargs="?", const="gpu", default=None, choices=["gpu", "cpu"],
+                    help="multi-rank rehearsal: 'gpu' = every rank uses cuda:0 and the ranks rendezvous over gloo; 'cpu' = "
+                         "no GPU at all, a step is a stand-in CPU op (checks spawn / rendezvous / barrier / max-over-ranks / "
+                         "rank-0 reporting; the number is not a result)")
+    return ap.parse_args()
 
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing above touched the GPU (importing torch does not).
+        from underwater_image_restoration_amd.shard import launch_local_ranks
+        return launch_local_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or start bare and let "
+              f"bench.py spawn them)", file=sys.stderr)
+        return 2
+    cpu_only = args.rehearse == "cpu"
     if args.rehearse:
         local = 0
-    torch.cuda.set_device(local)
+    if not cpu_only:
+        torch.cuda.set_device(local)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
+        backend = "gloo" if args.rehearse else "nccl"
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    try:
+        return worker(args, rank, world, dist, backend, cpu_only)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
 
-    from underwater_image_restoration_amd import ops
-    from underwater_image_restoration_amd.student import NAFNetWFIGate
-    from underwater_image_restoration_amd.daclip import DaCLIPVision
-    from underwater_image_restoration_amd.synth import (daclip_vision_param_shapes, student_param_shapes,
-                                                        synth_state_dict, synth_student_inputs)
 
-    mk = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
-    sd = synth_state_dict(student_param_shapes(**mk), seed=0)
-    model = NAFNetWFIGate(**mk, precision=args.precision)
-    model.load_state_dict(sd)
-    model = model.cuda().eval()
-    model.overlap_branches = not args.serial_branches
-    clip_sd = synth_state_dict(daclip_vision_param_shapes(), seed=1)
-    clip = DaCLIPVision(precision=args.precision)
-    clip.load_state_dict(clip_sd)
-    clip = clip.cuda().eval()
-    x, _, m = synth_student_inputs(args.batch, args.size, args.size, 512, 10, mask_hw=(7, 7), seed=1234 + rank)
-    clip_in = torch.randn(args.batch, 3, 224, 224, generator=torch.Generator().manual_seed(7 + rank))
-    x, m, clip_in = x.cuda(), m.cuda(), clip_in.cuda()
-
-    # a step = encode(clip view) -> consume(features); U/test.py:114-117: degra_features condition the net
-    enc_in = clip_in
-    # --dual-replica: two forwards in flight on two activation-buffer sets / streams (pipeline.DualReplicaRestorer)
-    from underwater_image_restoration_amd.pipeline import DualReplicaRestorer
-    dual = DualReplicaRestorer(model) if args.dual_replica else None
-
-    def consume(img_f, z_d):
-        return model(x, z_d, m) if dual is None else dual.submit(x, z_d, m)
-
-    mp_per_step = args.batch * args.size * args.size / 1e6
+def worker(args, rank: int, world: int, dist, backend, cpu_only: bool) -> int:
+    sync = (lambda: None) if cpu_only else torch.cuda.synchronize
+    ops = None
+    timed_out = {}          # what the last timed step produced (student workload: the restored batch, for parity)
+    extra_cfg = {}
+    scaling = "weak"
     wl_name = None
-    if args.workload == "tiled1080":     # configs[2]: one 1920x1080 frame through 256-px windows with a 32-px halo
-        from underwater_image_restoration_amd.tiling import TiledRestorer
-        frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(3 + rank)).cuda()
-        restorer = TiledRestorer(model, tile=256, halo=32, max_batch=30)
-        m1, c1 = m[:1].contiguous(), clip_in[:1].contiguous()
+    model = clip = None
+    steps = args.steps
 
-        enc_in = c1
+    if cpu_only:
+        buf = torch.zeros(1 << 16)
 
-        def consume(img_f, z_d):  # noqa: F811
-            return restorer(frame, z_d, m1)
-        mp_per_step = 1080 * 1920 / 1e6
-        wl_name = (f"BASELINE configs[2]: 1920x1080 frame, 60 halo windows of 256 px (32-px halo), DA-CLIP z_d, "
-                   f"{args.precision}")
-    elif args.workload == "sde":        # configs[3]: IR-SDE reverse sampling, B=8 at 256x256, T steps
-        from underwater_image_restoration_amd.sde import IRSDE
-        from underwater_image_restoration_amd.synth import unet_param_shapes
-        from underwater_image_restoration_amd.unet import ConditionalUNet
-        unet = ConditionalUNet(3, 3, 64, [1, 2, 4, 8], 512, True, True, precision=args.precision)
-        unet.load_state_dict(synth_state_dict(unet_param_shapes(), seed=2))
-        unet = unet.cuda().eval()
-        sde = IRSDE(max_sigma=50, T=100, sample_T=args.sde_steps, schedule="cosine", eps=0.005, device="cuda")
-        sde.set_model(unet)
-        Bs = 8
-        mu = x[:Bs].contiguous()
-        sde.set_mu(mu)
-        cin = clip_in[:Bs].contiguous()
-
-        enc_in = cin
-
-        def consume(img_f, deg_f):  # noqa: F811
-            xt = sde.noise_state(mu)
-            return sde.reverse_posterior(xt, text_context=deg_f, image_context=img_f)
-        mp_per_step = Bs * args.size * args.size / 1e6
-        wl_name = (f"BASELINE configs[3]: IR-SDE reverse_posterior, {args.sde_steps} ConditionalUNet steps, batch {Bs} at "
-                   f"{args.size}x{args.size}, DA-CLIP contexts, {args.precision}")
-    elif args.workload == "dataset512":  # configs[4]: 512x512 images, sharded over the ranks (weak scaling per step)
-        Bd = 4
-        xd, _, md = synth_student_inputs(Bd, 512, 512, 512, 10, mask_hw=(7, 7), seed=99 + rank)
-        xd, md, cd = xd.cuda(), md.cuda(), clip_in[:Bd].contiguous()
-
-        enc_in = cd
-
-        def consume(img_f, z_d):  # noqa: F811
-            return model(xd, z_d, md) if dual is None else dual.submit(xd, z_d, md)
-        mp_per_step = Bd * 512 * 512 / 1e6
-        wl_name = f"BASELINE configs[4]: 512x512 images, {Bd}/GPU per step, DA-CLIP z_d, {args.precision}"
-
-    # Every step runs BOTH halves inside the timed region.  By default the encode of step k+1 is enqueued on a second
-    # HIP stream before the consumer of step k (pipeline.ConditioningPrefetcher): its ~200 small launches fill CUs the
-    # consumer's kernels leave idle.  --no-overlap runs the two halves back to back on one stream.
-    from underwater_image_restoration_amd.pipeline import ConditioningPrefetcher
-    prefetch = None if args.no_overlap else ConditioningPrefetcher(clip)
-
-    def run_steps(k: int) -> None:
-        if prefetch is None:
+        def run_steps(k: int, timed: bool = False) -> None:
             for _ in range(k):
-                consume(*clip.encode_image(enc_in, control=True))
-            return
-        handle = prefetch.launch(enc_in) if k > 0 else None
-        for i in range(k):
-            feats = prefetch.take(handle)
-            if i + 1 < k:
-                handle = prefetch.launch(enc_in)
-            consume(*feats)
+                buf.add_(1.0)
+        mp_per_step = 0.0
+        wl_name = "CPU rehearsal of the launch path (no GPU work)"
+    else:
+        from underwater_image_restoration_amd import ops
+        from underwater_image_restoration_amd.daclip import DaCLIPVision
+        from underwater_image_restoration_amd.pipeline import ConditioningPrefetcher, DualReplicaRestorer
+        from underwater_image_restoration_amd.student import NAFNetWFIGate
+        from underwater_image_restoration_amd.synth import (daclip_vision_param_shapes, student_param_shapes,
+                                                            synth_state_dict, synth_student_inputs)
+        sd = synth_state_dict(student_param_shapes(**MK), seed=0)
+        model = NAFNetWFIGate(**MK, precision=args.precision)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        model.overlap_branches = not args.serial_branches
+        clip_sd = synth_state_dict(daclip_vision_param_shapes(), seed=1)
+        clip = DaCLIPVision(precision=args.precision)
+        clip.load_state_dict(clip_sd)
+        clip = clip.cuda().eval()
+        x, _, m = synth_student_inputs(args.batch, args.size, args.size, 512, 10, mask_hw=(7, 7), seed=1234 + rank)
+        clip_in = torch.randn(args.batch, 3, 224, 224, generator=torch.Generator().manual_seed(7 + rank))
+        x_cpu, m_cpu, clip_cpu = x[:1].clone(), m[:1].clone(), clip_in[:1].clone()
+        x, m, clip_in = x.cuda(), m.cuda(), clip_in.cuda()
+
+        # a step = encode(clip view) -> consume(features); U/test.py:114-117: degra_features condition the net
+        enc_in = clip_in
+        dual = DualReplicaRestorer(model) if args.dual_replica else None
+
+        def consume(img_f, z_d):
+            r = model(x, z_d, m) if dual is None else dual.submit(x, z_d, m)
+            timed_out["restored"] = r
+            return r
+
+        mp_per_step = args.batch * args.size * args.size / 1e6
+        if args.workload == "tiled1080":     # configs[2]: one 1920x1080 frame through 256-px windows with a 32-px halo
+            from underwater_image_restoration_amd.tiling import TiledRestorer
+            frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(3 + rank)).cuda()
+            restorer = TiledRestorer(model, tile=256, halo=32, max_batch=30)
+            m1, c1 = m[:1].contiguous(), clip_in[:1].contiguous()
+            enc_in = c1
+
+            def consume(img_f, z_d):  # noqa: F811
+                return restorer(frame, z_d, m1)
+            mp_per_step = 1080 * 1920 / 1e6
+            wl_name = (f"BASELINE configs[2]: 1920x1080 frame, 60 halo windows of 256 px (32-px halo), DA-CLIP z_d, "
+                       f"{args.precision}")
+        elif args.workload == "sde":        # configs[3]: IR-SDE reverse sampling, B=8 at 256x256, T steps
+            unet, sde, mu, cin = build_sde(args, x, clip_in)
+            enc_in = cin
+
+            def consume(img_f, deg_f):  # noqa: F811
+                xt = sde.noise_state(mu)
+                return sde.reverse_posterior(xt, text_context=deg_f, image_context=img_f)
+            mp_per_step = mu.shape[0] * args.size * args.size / 1e6
+            wl_name = (f"BASELINE configs[3]: IR-SDE reverse_posterior, {args.sde_steps} ConditionalUNet steps, batch "
+                       f"{mu.shape[0]} at {args.size}x{args.size}, DA-CLIP contexts, {args.precision}")
+        elif args.workload == "dataset512":  # configs[4] shapes, weak form: Bd images per rank and step
+            Bd, S = args.dataset_batch, args.dataset_size
+            xd, _, md = synth_student_inputs(Bd, S, S, 512, 10, mask_hw=(7, 7), seed=99 + rank)
+            xd, md, cd = xd.cuda(), md.cuda(), clip_in[:Bd].contiguous()
+            enc_in = cd
+
+            def consume(img_f, z_d):  # noqa: F811
+                return model(xd, z_d, md) if dual is None else dual.submit(xd, z_d, md)
+            mp_per_step = Bd * S * S / 1e6
+            wl_name = f"BASELINE configs[4] shapes: {S}x{S} images, {Bd}/GPU per step, DA-CLIP z_d, {args.precision}"
+
+        # Every step runs BOTH halves inside the timed region.  By default the encode of step k+1 is enqueued on a second
+        # HIP stream before the consumer of step k (pipeline.ConditioningPrefetcher): its ~200 small launches fill CUs the
+        # consumer's kernels leave idle.  --no-overlap runs the two halves back to back on one stream.
+        prefetch = None if args.no_overlap else ConditioningPrefetcher(clip)
+
+        def run_steps(k: int, timed: bool = False) -> None:
+            if prefetch is None:
+                for _ in range(k):
+                    consume(*clip.encode_image(enc_in, control=True))
+                return
+            handle = prefetch.launch(enc_in) if k > 0 else None
+            for i in range(k):
+                feats = prefetch.take(handle)
+                if i + 1 < k:
+                    handle = prefetch.launch(enc_in)
+                consume(*feats)
+
+        if args.workload == "dataset4096":   # configs[4], strong form: a fixed image set split over the ranks
+            from underwater_image_restoration_amd import shard
+            from underwater_image_restoration_amd.pipeline import restore_stream
+            S, Bd = args.dataset_size, args.dataset_batch
+            lo, hi = shard.shard_range(args.images, rank, world)
+            cnt = hi - lo
+            gen = torch.Generator(device="cuda").manual_seed(4096)   # image i is the same whatever the world size:
+            imgs = torch.empty(cnt, 3, S, S, device="cuda")          # every rank draws the whole sequence position-wise
+            clips = torch.empty(cnt, 3, 224, 224, device="cuda")
+            for i in range(cnt):
+                g = gen.manual_seed(100000 + lo + i)
+                imgs[i] = torch.rand(3, S, S, device="cuda", generator=g)
+                clips[i] = torch.randn(3, 224, 224, device="cuda", generator=g)
+            md1 = torch.rand(1, 10, 7, 7, generator=torch.Generator().manual_seed(11)).cuda()
+            acc = torch.zeros(3, dtype=torch.float64, device="cuda")      # [psnr_sum, ssim_sum, count]
+            kept = [] if args.gather else None
+
+            def batches(a: int, b: int):
+                for s in range(a, b, Bd):
+                    e = min(s + Bd, b)
+                    yield imgs[s:e], clips[s:e], md1.expand(e - s, -1, -1, -1).contiguous()
+
+            def run_range(a: int, b: int, record: bool) -> None:
+                pos = a
+                for out, _, _ in restore_stream(clip, lambda xx, zz, mm: model(xx, zz, mm), batches(a, b)):
+                    nb = out.shape[0]
+                    if record:
+                        met = ops.image_metrics(out, imgs[pos:pos + nb].contiguous())   # vs the degraded input (no GT)
+                        acc[0] += met[:, 2].double().sum()
+                        acc[1] += (1.0 - met[:, 0].double()).sum()
+                        acc[2] += nb
+                        if kept is not None:
+                            kept.append(out)
+                    pos += nb
+
+            def run_steps(k: int, timed: bool = False) -> None:  # noqa: F811
+                if timed:
+                    run_range(0, cnt, True)            # the whole shard, whatever --steps says
+                else:
+                    run_range(0, min(cnt, Bd * k), False)
+            steps = -(-cnt // Bd)
+            scaling = "strong"
+            mp_per_step = None
+            wl_name = (f"BASELINE configs[4]: {args.images} synthetic {S}x{S} images split over {world} rank(s) "
+                       f"(shard.shard_range), {Bd} per forward, DA-CLIP z_d, {args.precision}, metrics all-reduced")
+            extra_cfg = {"images_total": args.images, "images_this_rank": cnt}
 
     run_steps(args.warmup)
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    ops.event_timing(True)  # HIP events around the main kernel of every flash-attention call (uwir_flash_attn_probe)
+    sync()
+    if ops is not None:
+        ops.event_timing(True)  # HIP events around the main kernel of every flash-attention call (uwir_flash_attn_probe)
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
+    run_steps(steps, timed=True)
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    timings = ops.collect_event_timings()
-    ops.event_timing(False)
+    timings = ops.collect_event_timings() if ops is not None else []
+    if ops is not None:
+        ops.event_timing(False)
+    ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if args.rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()
+    metrics = None
+    if args.workload == "dataset4096" and not cpu_only:
+        from underwater_image_restoration_amd import shard
+        tot = shard.allreduce_metrics(acc.tolist(), "cuda")           # train_student.py:646 counterpart
+        per_rank = [0] * world
+        if dist is not None:
+            cts = torch.zeros(world, dtype=torch.float64, device="cuda")
+            cts[rank] = extra_cfg["images_this_rank"]
+            dist.all_reduce(cts)
+            per_rank = [int(v) for v in cts.tolist()]
+        else:
+            per_rank = [extra_cfg["images_this_rank"]]
+        if args.gather:
+            full = shard.gather_rows(torch.cat(kept) if kept else imgs[:0], args.images)
+            extra_cfg["gathered_on_rank0"] = None if full is None else list(full.shape)
+        metrics = {"images": int(tot[2]), "mean_psnr_vs_input_db": round(tot[0] / max(tot[2], 1), 3),
+                   "mean_ssim_vs_input": round(tot[1] / max(tot[2], 1), 5)}
+        extra_cfg["images_per_rank"] = per_rank
+        total_mp = args.images * args.dataset_size ** 2 / 1e6
 
-    if rank == 0:
-        mp = world * mp_per_step * args.steps
-        # dominant kernel: level-0 WTB flash attention (12 heads x hd 16, n = (S/2)^2): most FLOPs of the path
-        n0 = (args.size // 2) ** 2
-        dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
-        roof = None
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
-        if os.path.exists(tj) and args.batch == 16 and args.size == 256 and args.precision == "bf16":
-            with open(tj) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
-        if dom:
-            avg_ms = sum(dom) / len(dom)
-            fl = 4.0 * args.batch * 12 * float(n0) ** 2 * (args.size and 16)  # 4*B*heads*n^2*hd
-            ach = fl / (avg_ms * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS[args.precision]
-            roof = {"bound": "mfma", "kernel": "attn_stream_kernel<hd16,1V,QG4> (WTB level-0 attention, main launch only: HIP events armed "
-                              "through uwir_flash_attn_probe on the launch stream)", "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": len(dom)}
-        cpu = None
-        if args.cpu_baseline != "skip" and world == 1 and args.workload == "student":
+    if rank != 0:
+        return 0
+    mp = total_mp if args.workload == "dataset4096" and not cpu_only else world * mp_per_step * steps
+    roof = None
+    parity = None
+    cpu = None
+    if not cpu_only and args.workload == "student":
+        roof = dominant_roofline(args, timings)
+        if args.census != "skip" and world == 1:
+            kernels = run_census(args, ops, model, clip, x, m, clip_in)
+            if roof is not None:
+                roof["kernels"] = kernels
+        if args.cpu_baseline != "skip" and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            cpu = cpu_baseline(mk, sd, clip_sd, args.cpu_size, threads)
-        line = {
-            "metric": "restored megapixels/sec (whole node)", "value": round(mp / elapsed, 4),
-            "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if args.rehearse else ""),
-            "config": {"workload": f"BASELINE configs[1]: DA-CLIP ViT-B/32 encode_image(control=True) -> z_d (512) -> student "
-                                   f"NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
-                                   f"{args.precision} MFMA compute, masks (10,7,7)",
-                       "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
-                       "encode_overlap": "none" if args.no_overlap else "next step's encode on a second HIP stream",
-                       "branch_overlap": "none" if args.serial_branches else "SFFB on a second HIP stream under WTB",
-                       "forwards_in_flight": 2 if args.dual_replica else 1,
-                       "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
-                       "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * args.steps / elapsed / 1e12, 1)},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        if wl_name is not None:
-            line["config"] = {"workload": wl_name, "sharding": f"independent units x{world}"}
-            line["roofline"] = None  # the roofline leg is defined for the headline workload only
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+            cpu, ref0 = cpu_baseline(sd, clip_sd, x_cpu, m_cpu, clip_cpu, threads)
+            r = timed_out.get("restored")
+            if r is not None and dual is None:
+                got0 = r[0][0].detach().float().cpu()
+                err = (got0.double() - ref0[0].double())
+                mse = float((err ** 2).mean())
+                parity = {"max_abs": float(f"{float(err.abs().max()):.3e}"),
+                          "psnr_db": round(100.0 if mse < 1e-10 else 10.0 * float(torch.log10(torch.tensor(1.0 / mse))), 2),
+                          "against": "oracle (fp32 CPU restatement of the reference: DA-CLIP encode + student forward) on "
+                                     "image 0 of the last timed batch, same weights; GPU side is the timed pipeline "
+                                     f"({args.precision})",
+                          "tolerance": "fp32: max_abs <= 1e-4; bf16: PSNR >= 50 dB (PSNR delta <= 0.05 dB at a 30 dB target)"}
+    line = {
+        "metric": "restored megapixels/sec (whole node)", "value": round(mp / elapsed, 4),
+        "unit": "MP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": args.precision,
+        "data": "synthetic" + ("" if not args.rehearse else
+                               (" (REHEARSAL: ranks share one GPU)" if args.rehearse == "gpu" else " (REHEARSAL: no GPU work)")),
+        "config": {"workload": f"BASELINE configs[1]: DA-CLIP ViT-B/32 encode_image(control=True) -> z_d (512) -> student "
+                               f"NAFNetWFIGate forward, batch {args.batch}/GPU at {args.size}x{args.size}, "
+                               f"{args.precision} MFMA compute, masks (10,7,7)",
+                   "batch_per_gpu": args.batch, "size": args.size, "sharding": f"images x{world}",
+                   "encode_overlap": "none" if args.no_overlap else "next step's encode on a second HIP stream",
+                   "branch_overlap": "none" if args.serial_branches else "SFFB on a second HIP stream under WTB",
+                   "forwards_in_flight": 2 if args.dual_replica else 1,
+                   "algorithmic_tflop_per_step": round(student_flops(args.batch, args.size) / 1e12, 2),
+                   "achieved_tflops_whole_path": round(student_flops(args.batch, args.size) * world * steps / elapsed / 1e12, 1)},
+        "ranks": {"world_size": world, "backend": backend, "ranks_in_group": ranks_seen,
+                  "launched_by": "bench.py spawn" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ
+                  else ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")},
+        "roofline": roof, "parity": parity, "cpu_baseline": cpu,
+    }
+    if wl_name is not None:
+        line["config"] = {"workload": wl_name, "sharding": f"independent units x{world}", **extra_cfg}
+        line["roofline"] = None  # the roofline leg is defined for the headline workload only
+    if metrics is not None:
+        line["dataset_metrics"] = metrics
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def build_sde(args, x, clip_in):
+    from underwater_image_restoration_amd.sde import IRSDE
+    from underwater_image_restoration_amd.synth import synth_state_dict, unet_param_shapes
+    from underwater_image_restoration_amd.unet import ConditionalUNet
+    unet = ConditionalUNet(3, 3, 64, [1, 2, 4, 8], 512, True, True, precision=args.precision)
+    unet.load_state_dict(synth_state_dict(unet_param_shapes(), seed=2))
+    unet = unet.cuda().eval()
+    sde = IRSDE(max_sigma=50, T=100, sample_T=args.sde_steps, schedule="cosine", eps=0.005, device="cuda")
+    sde.set_model(unet)
+    Bs = min(8, x.shape[0])
+    mu = x[:Bs].contiguous()
+    sde.set_mu(mu)
+    return unet, sde, mu, clip_in[:Bs].contiguous()
+
+
+def dominant_roofline(args, timings):
+    """Dominant kernel: level-0 WTB flash attention (12 heads x hd 16, n = (S/2)^2): most FLOPs of the path."""
+    n0 = (args.size // 2) ** 2
+    dom = [ms for tag, ms in timings if tag[0] == "flash_attn" and tag[2] == n0 and tag[3] == 12]
+    if not dom:
+        return None
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
+    if not os.path.exists(tj):
+        tj = os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")
+    if os.path.exists(tj) and args.batch == 16 and args.size == 256 and args.precision == "bf16":
+        with open(tj) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+    avg_ms = sum(dom) / len(dom)
+    fl = 4.0 * args.batch * 12 * float(n0) ** 2 * 16   # 4*B*heads*n^2*hd
+    ach = fl / (avg_ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[args.precision]
+    # The ceiling that binds at hd = 16 is VALU issue, not the MFMA pipe (DESIGN.md section 4): per 32x32 score block
+    # a wave issues 16 v_exp_f32 (8 cycles each) + 8 v_cvt_pk_bf16_f32 (4) + 3 MFMA (8) = 184 cycles for 2*32*32*16*2
+    # FLOP -> 256 CUs x 4 SIMDs x clock / 184 blocks per second.
+    clock_ghz = 2.4
+    ceil_tf = 256 * 4 * clock_ghz * 1e9 / 184.0 * (4.0 * 32 * 32 * 16) / 1e12
+    return {"bound": "valu-exp", "kernel": "attn_stream_kernel<hd16,1V,QG4> (WTB level-0 attention, main launch only: HIP "
+                                           "events armed through uwir_flash_attn_probe on the launch stream)",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "avg_launch_ms": round(avg_ms, 4), "launches": len(dom),
+            "bound_note": "peak / frac are the dense bf16 MFMA peak (the honest MFMA fraction); the kernel's own ceiling is "
+                          "VALU issue of v_exp_f32 at head_dim 16: 184 issue cycles per 32x32 score block",
+            "valu_exp_ceiling_tflops": round(ceil_tf, 1), "frac_of_valu_exp_ceiling": round(ach / ceil_tf, 4),
+            "valu_exp_ceiling_clock_ghz": clock_ghz}
+
+
+def run_census(args, ops, model, clip, x, m, clip_in):
+    """One untimed pass of the student step and one IR-SDE UNet step (batch 8) on a single stream with HIP events around
+    every launcher -> achieved / peak per kernel class."""
+    ob = model.overlap_branches
+    model.overlap_branches = False
+    try:
+        ops.op_census(True)
+        _, z = clip.encode_image(clip_in, control=True)
+        torch.cuda.synchronize()
+        ops.collect_op_census()          # drop the DA-CLIP launches: the list is about the restoration kernels
+        ops.op_census(True)
+        model(x, z, m)
+        torch.cuda.synchronize()
+        rows = ops.collect_op_census()
+    finally:
+        ops.op_census(False)
+        model.overlap_branches = ob
+    table = census_table(rows, args.precision)
+    try:
+        unet, sde, mu, cin = build_sde(args, x, clip_in)
+        img_f, deg_f = clip.encode_image(cin, control=True)
+        xt = sde.noise_state(mu)
+        for _ in range(2):               # warm the UNet's buffers
+            pred = sde.noise_fn(xt, 50, text_context=deg_f, image_context=img_f)
+        ops.op_census(True)
+        pred = sde.noise_fn(xt, 50, text_context=deg_f, image_context=img_f)
+        sde.reverse_posterior_step(xt, pred, 50, out=xt)
+        torch.cuda.synchronize()
+        rows = ops.collect_op_census()
+        for e in census_table(rows, args.precision):
+            e["class"] = "IR-SDE UNet step (B=8): " + e["class"]
+            table.append(e)
+    finally:
+        ops.op_census(False)
+    return table
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -41,12 +41,27 @@ def on_operand_device(fn):
 
 # Optional HIP-event timing of selected launches (bench.py's roofline leg).  Events are recorded on
 # torch's current stream, which is the stream every kernel of this library is enqueued on.
-_TIMING = {"on": False, "events": []}
+_TIMING = {"on": False, "events": [], "all": False, "ops": []}
 
 
 def event_timing(enable: bool) -> None:
     _TIMING["on"] = enable
     _TIMING["events"] = []
+
+
+def op_census(enable: bool) -> None:
+    """Per-call HIP events around EVERY launcher below (bench.py's per-kernel-class roofline list).  Meant for one
+    untimed pass on a single stream: the events bracket whatever the call enqueues (for flash_attn that includes its
+    pack pre-pass), plus a few microseconds of launch gap."""
+    _TIMING["all"] = enable
+    _TIMING["ops"] = []
+
+
+def collect_op_census():
+    """-> list of (op name, args, kwargs, milliseconds); call after torch.cuda.synchronize()."""
+    out = [(n, a, k, s.elapsed_time(e)) for n, a, k, s, e in _TIMING["ops"]]
+    _TIMING["ops"] = []
+    return out
 
 
 def collect_event_timings():
@@ -412,3 +427,24 @@ def image_metrics(x: torch.Tensor, y: torch.Tensor, c1: float = 0.01 ** 2, c2: f
     _lib.check(lib.uwir_image_metrics(_p(x), _p(y), B, C_, H, W, c1, c2, _p(out), _p(ws), ws.numel() * 8, _stream(x)),
                "image_metrics")
     return out
+
+
+def _census_wrap(name: str, fn):
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        if not _TIMING["all"]:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        _TIMING["ops"].append((name, a, k, e0, e1))
+        return r
+    return wrapper
+
+
+for _n in ("dwt2", "idwt2", "ln2d_affine", "conv_gemm", "dwconv_ms", "flash_attn", "fft2_amp_phase", "ifft2_polar_add",
+           "affine_cast", "stem_conv3x3", "head_conv3x3", "sde_euler_step", "sde_posterior_step", "linear_attention",
+           "ln_rows", "groupnorm_affine", "geglu", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear"):
+    globals()[_n] = _census_wrap(_n, globals()[_n])
+del _n

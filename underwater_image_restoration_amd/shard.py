@@ -11,6 +11,10 @@ gather uses each sender's own direct link to the root.
 from __future__ import annotations
 
 import math
+import os
+import socket
+import subprocess
+import sys
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -102,3 +106,39 @@ def restore_frame_sharded(restorer, x: torch.Tensor, cond: torch.Tensor, masks: 
     if rank != dst:
         return None
     return restorer.stitch(allw.transpose(0, 1), tiles, H, W)
+
+
+def launch_local_ranks(script: str, argv: Sequence[str], n_ranks: int, extra_env: Optional[dict] = None) -> int:
+    """Start ``n_ranks`` copies of ``python script *argv`` on THIS node, one per GPU, with the ``torchrun`` environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and wait for them: what
+    ``python -m torch.distributed.run --nproc-per-node N`` does, for callers that were started as a bare
+    ``python bench.py --gpus N``.  Must be called BEFORE the calling process touches the GPU (it only waits; a process
+    that has initialised HIP must not exec, and holding a context on GPU 0 next to rank 0 would skew the run).
+    Rank 0's stdout is relayed line by line; every rank inherits stderr.  If a rank fails the others are terminated
+    (by PID).  -> 0 when every rank exited 0, else the first non-zero exit code."""
+    if n_ranks < 1:
+        raise ValueError("n_ranks must be >= 1")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n_ranks))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-u", script, *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    for line in procs[0].stdout:          # rank 0 prints the result line(s)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = 0
+    for p in procs:
+        code = p.wait()
+        if code != 0 and rc == 0:
+            rc = code
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+    return rc
