@@ -159,9 +159,10 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * scale = 1/sqrt(hd) normally; scale == 0 means "q is already multiplied by (1/sqrt(hd))*log2(e)" (the producing
  * GEMM applied it through col_scale), which saves one bf16 rounding of q.
  * workspace (optional, >= uwir_flash_attn_workspace_bytes(B, n, heads), 4-byte aligned): enables the bf16 fast path --
- * a pre-pass stores max_k |k|^2 per (b, head) there; where the a-priori score bound |c q| * max|k| is <= 60 (log2
- * units) exp2 cannot leave the fp32/bf16 range, the (mathematically cancelling) softmax shift is dropped and no
- * running max / rescale is computed; blocks with a larger bound run the online-max loop.
+ * a pre-pass stores max_k |k|^2 per (b, head) there; where the a-priori score bound ub = |c q| * max|k| is <= 90 (log2
+ * units) exp2 cannot leave the fp32/bf16 range (P = 2^s in [2^-90, 2^90] is a normal bf16; the fp32 row sum l is
+ * <= n 2^90 <= 2^107 for n <= 2^17; O <= l max|v|, finite for |v| < 2^20), the (mathematically cancelling) softmax
+ * shift is dropped and no running max / rescale is computed; blocks with a larger bound run the online-max loop.
  * With >= uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) bytes, 256-byte aligned, long bf16 sequences with
  * hd 16 or 32 (n >= 2048, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
  * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier.  The

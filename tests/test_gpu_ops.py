@@ -362,7 +362,8 @@ def test_flash_attn_forced_rescale(ops, prec):
     assert err(o[None], ref) < (2e-5 if prec == "fp32" else 2e-2)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 128, 128), (2, 20, 8, 32), (1, 4, 1, 1), (1, 8, 12, 10), (1, 4, 2, 4)])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 128, 128), (2, 20, 8, 32), (1, 4, 1, 1), (1, 8, 12, 10), (1, 4, 2, 4),
+                                   (1, 8, 68, 120)])   # 68 x 120: the level-2 map of a 544 x 960 frame, direct-DFT path
 def test_fft_roundtrip_and_parts(ops, shape):
     b, c, h, w = shape
     g = torch.Generator().manual_seed(9)
@@ -681,6 +682,43 @@ def test_flash_attn_packed_stream(ops, cfg):
     assert torch.equal(o_p[:n], o_o[:n]) and bool(torch.isfinite(o_p).all())
     if b > 1:
         assert err(o_p[n:], refs[0][n:]) < 3e-2
+
+
+def test_flash_attn_bound_band_60_to_90(ops):
+    """The no-shift fast path is taken while the a-priori score bound ub = |c q| max|k| is <= 90 (log2 units).  Drive the
+    (60, 90] band on the packed-stream kernel at n = 65536: every query has ub ~ 85 and keys aligned with / against the
+    common query direction give scores from about -85 to +85, i.e. P up to 2^85 and row sums up to n * 2^85 in fp32."""
+    b, n, heads, hd = 1, 65536, 2, 16
+    g = torch.Generator().manual_seed(29)
+    c = 1.4426950408889634 / math.sqrt(hd)
+    u = torch.nn.functional.normalize(torch.randn(heads, hd, generator=g), dim=-1)
+    qd = torch.nn.functional.normalize(u[None] + 0.05 * torch.randn(n, heads, hd, generator=g), dim=-1)
+    q = (qd * (8.5 / c)).reshape(n, heads * hd)                        # |c q| = 8.5
+    sgn = torch.where(torch.rand(n, heads, 1, generator=g) < 0.5, -1.0, 1.0)
+    kd = torch.nn.functional.normalize(u[None] * sgn + 0.3 * torch.randn(n, heads, hd, generator=g), dim=-1)
+    k = (kd * (10.0 * torch.rand(n, heads, 1, generator=g))).reshape(n, heads * hd)
+    k[7] = (u * 10.0).reshape(-1)                                      # max|k| = 10 exactly -> ub = 85 (+ margin)
+    v = torch.randn(n, heads * hd, generator=g)
+    q, k, v = q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda()
+    ub = float((q.float().reshape(n, heads, hd).norm(dim=-1) * c).max() * k.float().reshape(n, heads, hd).norm(dim=-1).max())
+    assert 60.0 < ub * 1.002 + 1e-3 <= 90.0
+    ref = torch.empty(n, heads * hd, dtype=torch.float64, device="cuda")
+    smax = 0.0
+    for h in range(heads):
+        cols = slice(h * hd, (h + 1) * hd)
+        kk, vv = k[:, cols].double(), v[:, cols].double()
+        for r0 in range(0, n, 4096):
+            sc = q[r0:r0 + 4096, cols].double() @ kk.T / math.sqrt(hd)
+            smax = max(smax, float(sc.abs().max()) * 1.4426950408889634)
+            ref[r0:r0 + 4096, cols] = torch.softmax(sc, dim=-1) @ vv
+    assert smax > 60.0                                                 # scores really reach the band (log2 units)
+    o_f = torch.empty(n, heads * hd, device="cuda")
+    o_o = torch.empty(n, heads * hd, device="cuda")
+    ops.flash_attn(q, k, v, None, b, n, heads, hd, 1.0 / math.sqrt(hd), o_f, None)
+    ops.flash_attn(q, k, v, None, b, n, heads, hd, 1.0 / math.sqrt(hd), o_o, None, fast=False)
+    assert bool(torch.isfinite(o_f).all())
+    assert err(o_f, ref) < 3e-2 and err(o_o, ref) < 3e-2
+    assert not torch.equal(o_f, o_o)                                   # the two launches are different kernels
 
 
 def test_affine_cast(ops):

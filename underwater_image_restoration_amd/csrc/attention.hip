@@ -290,8 +290,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
 
     // ---- bf16 fast path: a-priori score bound.  |c*q.k| <= |c*q| * max_k|k| =: ub (Cauchy-Schwarz on the exact bf16
     // operands).  The softmax shift is a per-query constant that cancels in O / l, so it only has to keep exp2 in
-    // range: with ub <= 60 every exp2 argument lies in [-60, 60], P (bf16, 8-bit exponent) and the fp32 sums
-    // (<= n * 2^60) stay normal, and NO shift is applied at all -- no running max, no rescale, no extra MFMA k-step,
+    // range: with ub <= 90 every exp2 argument lies in [-90, 90], P = 2^s (bf16, 8-bit exponent) is normal, the fp32
+    // row sums l <= n * 2^90 <= 2^107 (n <= 2^17) and O <= l * max|v| (finite for |v| < 2^20) stay in range, and NO
+    // shift is applied at all -- no running max, no rescale, no extra MFMA k-step,
     // same relative accuracy as the online-max form.  Waves with a larger bound (wave-uniform test) take the
     // online-max loop; both loops stage the same tiles behind the same barriers.
     bool fast = false;
