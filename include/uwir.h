@@ -263,6 +263,21 @@ size_t uwir_linattn_workspace_bytes(int B, int n, int heads);
 int uwir_linear_attention(const void* qkv, int dtype, int ld, int B, int n, int heads, void* out, int out_dtype, int ldo,
                           void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
+/* ---- the whole Residual(PreNorm(dim, LinearAttention(dim))) block, fused (bf16 MFMA operands, fp32 accumulation) ------
+ * U/module_util.py:27-33 (Residual), :77-97 (channel LayerNorm, gain only, PreNorm), :157-185 (LinearAttention incl.
+ * to_out = Conv2d(128, dim, 1) + LayerNorm), wired by U/DenoisingUNet_arch.py:81-88:
+ *   out[m,:] = LN_{g_out}( W_out . LA( W_qkv . LN_{g_pre}(x)[.] )[m] + b_out ) + x[m,:]
+ * Everything after the context reduction is row-local, so the block is two passes over x (+ a tiny combine): pass 1
+ * builds ctx[b,h] = softmax_n(k) v^T / n with an online max over the rows, pass 2 does q-softmax, ctx product, to_out,
+ * the output LayerNorm and the residual.  x, out fp32 [B*n, ld]; w_qkv bf16 [3*heads*32, dim] (rows q | k | v),
+ * w_out bf16 [dim, heads*32]; heads must be 4, dim 64 / 128 / 256 (the reference's LinearAttention sizes); out may not
+ * alias x.  workspace >= uwir_linattn_block_workspace_bytes(B, n), 16-byte aligned.  Same function as the unfused
+ * sequence uwir_ln_rows -> uwir_conv_gemm -> uwir_linear_attention -> uwir_conv_gemm -> uwir_ln_rows to bf16 rounding. */
+size_t uwir_linattn_block_workspace_bytes(int B, int n);
+int uwir_linattn_block(const float* x, int ldx, int B, int n, int dim, int heads, const float* g_pre, const void* w_qkv,
+                       const void* w_out, const float* b_out, const float* g_out, float eps, float* out, int ldo,
+                       void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+
 /* ---- GEGLU gate, U/attention.py:37-44: h [M, 2F] = [value | gate] -> out [M, F] = value * gelu(gate) (exact GELU);
  * h and out share dtype. */
 int uwir_geglu(const void* h, int dtype, size_t ldh, int M, int F, void* out, size_t ldo, uwir_stream_t stream);

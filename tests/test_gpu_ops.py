@@ -574,6 +574,45 @@ def test_linear_attention(ops, io):
         assert float(out[:, hd:].float().min()) == 2.0
 
 
+@pytest.mark.parametrize("cfg", [(2, 100, 64), (1, 1500, 128), (2, 64, 256), (1, 4100, 64), (8, 16384, 64)])
+def test_linattn_block_fused(ops, cfg):
+    """The fused Residual(PreNorm(LinearAttention)) block (csrc/linattn.hip) against an fp64 evaluation of
+    module_util.py:27-33,77-97,157-185 on the same bf16-rounded weights; ragged n (not a multiple of the 32-row MFMA
+    group or the 64-row tile), several chunks per batch element (online max across tiles and chunks), large |k|."""
+    b, n, dim = cfg
+    g = torch.Generator().manual_seed(31)
+    ld = dim + 4
+    x = torch.randn(b * n, ld, generator=g) * 1.5 + 0.3
+    x[: n // 2, :dim] *= 3.0                                           # k grows along the rows: the running max must move
+    g_pre, g_out = torch.rand(dim, generator=g) + 0.5, torch.rand(dim, generator=g) + 0.5
+    w_qkv = (torch.randn(384, dim, generator=g) * (2.0 / dim ** 0.5)).bfloat16()
+    w_out = (torch.randn(dim, 128, generator=g) * (1.0 / 128 ** 0.5)).bfloat16()
+    b_out = torch.randn(dim, generator=g) * 0.1
+
+    def chan_ln(t, gain):                                               # (rows, C): module_util.py:77-86
+        mu = t.mean(dim=1, keepdim=True)
+        var = ((t - mu) ** 2).mean(dim=1, keepdim=True)
+        return (t - mu) / torch.sqrt(var + 1e-5) * gain
+
+    xd = x[:, :dim].double().cuda()
+    xn = chan_ln(xd, g_pre.double().cuda())
+    qkv = xn @ w_qkv.double().cuda().T
+    q, k, v = (qkv[:, i * 128:(i + 1) * 128].reshape(b, n, 4, 32).permute(0, 2, 3, 1) for i in range(3))
+    ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v / n)
+    la = torch.einsum("bhde,bhdn->bhen", ctx, q.softmax(dim=-2) * 32 ** -0.5).permute(0, 3, 1, 2).reshape(b * n, 128)
+    ref = chan_ln(la @ w_out.double().cuda().T + b_out.double().cuda(), g_out.double().cuda()) + xd
+    out = torch.full((b * n, dim + 8), 7.0, device="cuda")
+    ws = torch.empty(ops.linattn_block_workspace_bytes(b, n) // 4, device="cuda")
+    ops.linattn_block(x.cuda()[:, :dim], b, n, dim, g_pre.cuda(), w_qkv.cuda(), w_out.cuda(), b_out.cuda(), g_out.cuda(),
+                      out[:, :dim], ws)
+    e = err(out[:, :dim], ref)
+    # the LayerNorm'ed attention term has unit scale: bf16 operands (xn, E, V, P, ctx, Y) give ~1e-2 absolute
+    print(f"\n[linattn_block b{b} n{n} dim{dim}] max abs err {e:.3e} (|ref|max {float(ref.abs().max()):.2f})")
+    assert e < 6e-2 and float(out[:, dim:].min()) == 7.0
+    rel_l2 = float((out[:, :dim].double() - ref).norm() / (ref - xd).norm())
+    assert rel_l2 < 1.5e-2
+
+
 def test_geglu_softmax_input_tail(ops):
     g = torch.Generator().manual_seed(18)
     h = torch.randn(37, 2 * 64, generator=g)

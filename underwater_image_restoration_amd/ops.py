@@ -384,6 +384,24 @@ def linear_attention(qkv: torch.Tensor, B: int, n: int, heads: int, out: torch.T
                "linear_attention")
 
 
+def linattn_block_workspace_bytes(B: int, n: int) -> int:
+    return int(_lib.load().uwir_linattn_block_workspace_bytes(B, n))
+
+
+def linattn_block(x: torch.Tensor, B: int, n: int, dim: int, g_pre, w_qkv, w_out, b_out, g_out, out: torch.Tensor,
+                  workspace: torch.Tensor, eps: float = 1e-5, heads: int = 4) -> None:
+    """out = LN_gout(W_out . LinearAttention(W_qkv . LN_gpre(x)) + b_out) + x, fused (bf16 MFMA); see uwir.h."""
+    _f32(x, g_pre, b_out, g_out, out)
+    if w_qkv.dtype != torch.bfloat16 or w_out.dtype != torch.bfloat16 or not w_qkv.is_contiguous() or not w_out.is_contiguous():
+        raise TypeError("linattn_block: weights must be contiguous bf16")
+    if tuple(w_qkv.shape) != (3 * heads * 32, dim) or tuple(w_out.shape) != (dim, heads * 32):
+        raise ValueError("linattn_block: weight shapes must be [3*heads*32, dim] and [dim, heads*32]")
+    lib = _lib.load()
+    _lib.check(lib.uwir_linattn_block(_p(x), _ld(x), B, n, dim, heads, _p(g_pre), _p(w_qkv), _p(w_out), _p(b_out), _p(g_out),
+                                      eps, _p(out), _ld(out), _p(workspace), workspace.numel() * workspace.element_size(),
+                                      _stream(x)), "linattn_block")
+
+
 def geglu(h: torch.Tensor, out: torch.Tensor) -> None:
     lib = _lib.load()
     M, F2 = h.shape
@@ -445,6 +463,6 @@ def _census_wrap(name: str, fn):
 
 for _n in ("dwt2", "idwt2", "ln2d_affine", "conv_gemm", "dwconv_ms", "flash_attn", "fft2_amp_phase", "ifft2_polar_add",
            "affine_cast", "stem_conv3x3", "head_conv3x3", "sde_euler_step", "sde_posterior_step", "linear_attention",
-           "ln_rows", "groupnorm_affine", "geglu", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear"):
+           "ln_rows", "groupnorm_affine", "geglu", "linattn_block", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear"):
     globals()[_n] = _census_wrap(_n, globals()[_n])
 del _n

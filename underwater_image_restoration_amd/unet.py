@@ -65,6 +65,7 @@ class ConditionalUNet(nn.Module):
                     p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
         self._pack: Optional[dict] = None
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self.fused_linattn = True            # bf16: Residual(PreNorm(LinearAttention)) as two fused passes (csrc/linattn.hip)
         self._emb_cache: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ parameters
@@ -234,6 +235,11 @@ class ConditionalUNet(nn.Module):
         """Residual(PreNorm(dim, LinearAttention | SpatialTransformer)): x [M, dim] view -> out [M, dim] view."""
         M, n, dev, adt, f32 = B * H * W, H * W, x.device, self._pack["adt"], torch.float32
         dim = a["g_pre"].numel()
+        if a["kind"] == "linear" and adt == torch.bfloat16 and dim in (64, 128, 256) and self.fused_linattn:
+            # the whole Residual(PreNorm(LinearAttention)) block in two passes over x (csrc/linattn.hip)
+            ws = self._buf("laf_ws", 1, ops.linattn_block_workspace_bytes(B, n) // 4, f32, dev)
+            ops.linattn_block(x, B, n, dim, a["g_pre"], a["w_qkv"], a["w_out"], a["b_out"], a["g_out"], out, ws)
+            return
         if a["kind"] == "linear":
             xn = self._buf(tag + "xn", M, dim, adt, dev)
             ops.ln_rows(x, a["g_pre"], None, xn, 1e-5)
