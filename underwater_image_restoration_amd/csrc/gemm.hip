@@ -11,6 +11,7 @@
 // CONSECUTIVE output channels of one pixel: the epilogue (bias, per-sample bias, activation,
 // affine residual, gate blend, depth-to-space scatter) works on 16-byte vectors.
 #include "common.h"
+#include <type_traits>
 
 struct GemmP {
     uwir_gemm_args a;
@@ -683,16 +684,15 @@ static bool glds_eligible(const uwir_gemm_args& g, int K) {
 // shifted views of it: the B operand of tap (ky, kx) for pixel (y, x) is LDS row (y+ky)*18 + x+kx.  Weights stream
 // through LDS three taps (one filter row) at a time.  Register prefetch of the next stage overlaps the MFMAs.
 // ------------------------------------------------------------------------------------------
-#define HC_TH 8
 #define HC_TW 16
 #define HC_PW (HC_TW + 2)
-#define HC_NPIX ((HC_TH + 2) * HC_PW)   // 180
 #define HC_BK 32
 #define HC_STR 40                        // LDS row stride in bf16 (32 + 8 pad): conflict-free 16-byte fragment reads
 #define HC_TG 3                          // taps per weight stage
 
-template <typename TA, int BN>
+template <typename TA, int BN, int HC_TH>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
+    constexpr int HC_NPIX = (HC_TH + 2) * HC_PW;               // 180 (8-row tile) or 324 (16-row tile)
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N, TM = HC_TH / WAVES_M, TN = 4;
     constexpr int A_ITEMS = HC_NPIX * (HC_BK / 8);                    // 16-byte (8 x bf16) pieces of the halo tile
     constexpr int A_IT = (A_ITEMS + 255) / 256;
@@ -719,100 +719,98 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
     const TA* __restrict__ Aptr = (const TA*)g.A;
     const bf16_t* __restrict__ Wptr = (const bf16_t*)g.Wt;
 
-    // ---- per-thread staging descriptors of the halo tile (fixed over the chunk loop): source pixel offset or -1
-    long long a_off[A_IT];
-    int a_ch[A_IT];
+    // ---- per-thread staging descriptors, fixed over the stage loop.  Everything that does not depend on the stage is
+    // computed ONCE (the first version redid the index arithmetic and 64-bit address products per stage and predicated
+    // every load: ~180 VALU instructions and 28 exec-mask branches around 24 MFMAs per stage, VALU-active 59 % of the
+    // kernel).  Loads are unconditional from clamped addresses; zero padding is a select at the LDS store.
+    static_assert(W_ITEMS % 256 == 0, "weight stage must be whole iterations");
+    const TA* a_ptr[A_IT];
+    int a_lds[A_IT];          // LDS element offset of the piece, or -1 when this thread has no item in iteration `it`
+    unsigned a_ok = 0;        // bit it: the pixel is inside the image (else the piece is zero padding)
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int item = tid + 256 * it;
         const int pix = item / (HC_BK / 8), piece = item % (HC_BK / 8);
         const int iy = y0 + pix / HC_PW - 1, ix = x0 + pix % HC_PW - 1;   // coordinates in the (upsampled) input image
         const bool ok = item < A_ITEMS && iy >= 0 && iy < OH && ix >= 0 && ix < OW;
-        a_off[it] = ok ? (((long long)b * g.H + (iy >> g.ups)) * g.W + (ix >> g.ups)) * g.lda + piece * 8 : -1;
-        a_ch[it] = piece * 8;
+        if (ok) a_ok |= 1u << it;
+        const int cy = ok ? iy : 0, cx = ok ? ix : 0;
+        a_ptr[it] = Aptr + (((size_t)b * g.H + (cy >> g.ups)) * g.W + (cx >> g.ups)) * g.lda + piece * 8;
+        a_lds[it] = item < A_ITEMS ? pix * HC_STR + piece * 8 : -1;
+    }
+    const bf16_t* w_ptr[W_IT];
+    int w_lds[W_IT];
+    unsigned w_ok = 0;
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int item = tid + 256 * it;
+        const int row = item / (HC_BK / 8), piece = item % (HC_BK / 8);   // row = tap_local * BN + channel
+        const int tapl = row / BN, nl = row % BN, nn = n0 + nl;
+        if (nn < N) w_ok |= 1u << it;
+        w_ptr[it] = Wptr + (size_t)min(nn, N - 1) * K + tapl * C + piece * 8;
+        w_lds[it] = (tapl * BN + chan_perm(nl)) * HC_STR + piece * 8;      // LDS row pi(n)
     }
     RawChunk<TA, 8> ra[A_IT];
     bf16x8 rw[W_IT];
 
     const int nchunks = C / HC_BK;
-    const int nstages = nchunks * (9 / HC_TG);
-    auto load_stage = [&](int st) {
-        const int chunk = st / (9 / HC_TG), grp = st % (9 / HC_TG);
-        const int c0 = chunk * HC_BK;
-        if (grp == 0) {
+    auto load_a = [&](int c0) {
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                if (a_off[it] >= 0) {
-                    const TA* src = Aptr + a_off[it] + c0;
-                    if constexpr (sizeof(TA) == 4) {
-                        ra[it].lo = *reinterpret_cast<const float4*>(src);
-                        ra[it].hi = *reinterpret_cast<const float4*>(src + 4);
-                    } else {
-                        ra[it].v = *reinterpret_cast<const bf16x8*>(src);
-                    }
-                }
+        for (int it = 0; it < A_IT; ++it) {
+            const TA* src = a_ptr[it] + c0;
+            if constexpr (sizeof(TA) == 4) {
+                ra[it].lo = *reinterpret_cast<const float4*>(src);
+                ra[it].hi = *reinterpret_cast<const float4*>(src + 4);
+            } else {
+                ra[it].v = *reinterpret_cast<const bf16x8*>(src);
             }
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int item = tid + 256 * it;
-            const int row = item / (HC_BK / 8), piece = item % (HC_BK / 8);   // row = tap_local * BN + channel
-            const int tapl = row / BN, nn = n0 + row % BN;
-            bf16x8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
-            if (item < W_ITEMS && nn < N)
-                z = *reinterpret_cast<const bf16x8*>(Wptr + (size_t)nn * K + (size_t)(grp * HC_TG + tapl) * C + c0 + piece * 8);
-            rw[it] = z;
         }
     };
-    auto store_stage = [&](int st) {
-        const int chunk = st / (9 / HC_TG), grp = st % (9 / HC_TG);
-        const int c0 = chunk * HC_BK;
-        if (grp == 0) {
+    auto load_w = [&](int woff) {   // woff = (filter row * 3) * C + c0: block-uniform
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const int item = tid + 256 * it;
-                if (item >= A_ITEMS) continue;
-                const int pix = item / (HC_BK / 8);
-                bf16x8 o;
-                if (a_off[it] >= 0) {
-                    float v[8];
-                    if constexpr (sizeof(TA) == 4) {
-                        v[0] = ra[it].lo.x; v[1] = ra[it].lo.y; v[2] = ra[it].lo.z; v[3] = ra[it].lo.w;
-                        v[4] = ra[it].hi.x; v[5] = ra[it].hi.y; v[6] = ra[it].hi.z; v[7] = ra[it].hi.w;
-                    } else {
+        for (int it = 0; it < W_IT; ++it) rw[it] = *reinterpret_cast<const bf16x8*>(w_ptr[it] + woff);
+    };
+    auto store_a = [&](int c0) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (float)ra[it].v[j];
-                    }
-                    if (g.a_scale) {
-                        const float* sc = g.a_scale + (size_t)b * C + c0 + a_ch[it];
-                        const float* sh = g.a_shift + (size_t)b * C + c0 + a_ch[it];
+        for (int it = 0; it < A_IT; ++it) {
+            if (a_lds[it] < 0) continue;
+            float v[8];
+            if constexpr (sizeof(TA) == 4) {
+                v[0] = ra[it].lo.x; v[1] = ra[it].lo.y; v[2] = ra[it].lo.z; v[3] = ra[it].lo.w;
+                v[4] = ra[it].hi.x; v[5] = ra[it].hi.y; v[6] = ra[it].hi.z; v[7] = ra[it].hi.w;
+            } else {
 #pragma unroll
-                        for (int j = 0; j < 8; j += 4) {
-                            float4 s4 = load4(sc + j), h4 = load4(sh + j);
-                            v[j] = fmaf(v[j], s4.x, h4.x);
-                            v[j + 1] = fmaf(v[j + 1], s4.y, h4.y);
-                            v[j + 2] = fmaf(v[j + 2], s4.z, h4.z);
-                            v[j + 3] = fmaf(v[j + 3], s4.w, h4.w);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
-                }
-                *reinterpret_cast<bf16x8*>(&sA[pix * HC_STR + a_ch[it]]) = o;
+                for (int j = 0; j < 8; ++j) v[j] = (float)ra[it].v[j];
             }
+            if (g.a_scale) {   // block-uniform
+                const int ch = c0 + (a_lds[it] % HC_STR);
+                const float* sc = g.a_scale + (size_t)b * C + ch;
+                const float* sh = g.a_shift + (size_t)b * C + ch;
+#pragma unroll
+                for (int j = 0; j < 8; j += 4) {
+                    float4 s4 = load4(sc + j), h4 = load4(sh + j);
+                    v[j] = fmaf(v[j], s4.x, h4.x);
+                    v[j + 1] = fmaf(v[j + 1], s4.y, h4.y);
+                    v[j + 2] = fmaf(v[j + 2], s4.z, h4.z);
+                    v[j + 3] = fmaf(v[j + 3], s4.w, h4.w);
+                }
+            }
+            const bool ok = (a_ok >> it) & 1;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(ok ? v[j] : 0.f);   // padding pads the NORMALISED image
+            *reinterpret_cast<bf16x8*>(&sA[a_lds[it]]) = o;
         }
+    };
+    auto store_w = [&]() {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
-            const int item = tid + 256 * it;
-            if (item >= W_ITEMS) continue;
-            const int row = item / (HC_BK / 8), piece = item % (HC_BK / 8);
-            const int tapl = row / BN, nl = row % BN;
-            *reinterpret_cast<bf16x8*>(&sW[(tapl * BN + chan_perm(nl)) * HC_STR + piece * 8]) = rw[it];  // LDS row pi(n)
+            bf16x8 o = rw[it];
+            if (!((w_ok >> it) & 1)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(&sW[w_lds[it]]) = o;
         }
     };
 
@@ -823,18 +821,20 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     const int wr0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * 64;   // first output row / channel of this wave
+    const bf16_t* a_rd = &sA[(wr0 * HC_PW + fr) * HC_STR + fq * 8];       // + ((i + ky) * HC_PW + kx) * HC_STR: immediates
+    const bf16_t* w_rd = &sW[(wn0 + fr) * HC_STR + fq * 8];               // + (kx * BN + j * 16) * HC_STR
 
-    auto compute = [&](int st) {
-        const int grp = st % (9 / HC_TG);   // taps grp*3 .. grp*3+2 = filter row ky = grp, kx = 0..2
+    // filter row ky = grp (compile-time): taps grp*3 .. grp*3+2
+    auto compute = [&](auto grp_tag) {
+        constexpr int grp = decltype(grp_tag)::value;
 #pragma unroll
         for (int tapl = 0; tapl < HC_TG; ++tapl) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(&sA[((wr0 + i + grp) * HC_PW + fr + tapl) * HC_STR + fq * 8]);
+                fa[i] = *reinterpret_cast<const bf16x8*>(a_rd + ((i + grp) * HC_PW + tapl) * HC_STR);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8*>(&sW[(tapl * BN + wn0 + j * 16 + fr) * HC_STR + fq * 8]);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(w_rd + (tapl * BN + j * 16) * HC_STR);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -843,13 +843,30 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         }
     };
 
-    load_stage(0);
-    for (int st = 0; st < nstages; ++st) {
-        if (st) __syncthreads();          // every wave is done with the previous stage's LDS image
-        store_stage(st);
+    load_a(0);
+    load_w(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * HC_BK;
+        // ---- filter row 0 (+ the chunk's halo tile)
+        if (chunk) __syncthreads();       // every wave is done with the previous stage's LDS image
+        store_a(c0);
+        store_w();
         __syncthreads();
-        if (st + 1 < nstages) load_stage(st + 1);
-        compute(st);
+        load_w(1 * HC_TG * C + c0);
+        compute(std::integral_constant<int, 0>{});
+        // ---- filter row 1
+        __syncthreads();
+        store_w();
+        __syncthreads();
+        load_w(2 * HC_TG * C + c0);
+        if (chunk + 1 < nchunks) load_a(c0 + HC_BK);   // two compute stages ahead of its use
+        compute(std::integral_constant<int, 1>{});
+        // ---- filter row 2
+        __syncthreads();
+        store_w();
+        __syncthreads();
+        if (chunk + 1 < nchunks) load_w(c0 + HC_BK);
+        compute(std::integral_constant<int, 2>{});
     }
 
     int mrow[TM], mcnt[TM];
@@ -867,18 +884,28 @@ static bool halo_eligible(const uwir_gemm_args& g) {
            g.OH == (g.H << g.ups) && g.OW == (g.W << g.ups) && g.lda % 8 == 0;
 }
 
+static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
+                              // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
+extern "C" void uwir_conv_variant(int th16) { g_halo_th16 = th16; }
+
 template <typename TA>
 static int launch_halo(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
-    const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, HC_TH) * ceil_div(p.a.OW, HC_TW);
+    // optional 16-row tiles (256 pixels per block: TM doubles, i.e. half the weight re-staging and barriers per pixel and
+    // 0.5 instead of 0.75 LDS fragment reads per MFMA at N = 64): measured no faster, off by default
+    const long long mt16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW);
+    const bool th16 = g_halo_th16 && p.a.N <= 64 && mt16 >= 1024;
+    const int th = th16 ? 16 : 8;
+    const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
     int bn = p.a.N <= 64 ? 64 : 128;
     if (bn == 128 && mtiles * ceil_div(p.a.N, 128) < 512) bn = 64;
     p.tiles_n = ceil_div(p.a.N, bn);
     const long long nb = mtiles * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
-    if (bn == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64>), dim3(p.nblocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 128>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    if (bn == 64 && th16) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 16>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 128, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm(halo)");
     return UWIR_OK;
 }
