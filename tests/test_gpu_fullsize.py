@@ -76,6 +76,15 @@ def test_configs2_1080p_tiling_invariants(student):
     assert a.shape == frame.shape and bool(torch.isfinite(a).all())
     assert psnr(a, b) > 60.0
     assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    # configs[2] names fp32 as well: the same frame through the exact-fp32 path, and bf16 against it
+    model.set_precision("fp32")
+    try:
+        f32 = TiledRestorer(model, tile=256, halo=32, max_batch=30)(frame, z, m)
+    finally:
+        model.set_precision("bf16")
+    assert bool(torch.isfinite(f32).all()) and float(f32.min()) >= 0.0 and float(f32.max()) <= 1.0
+    print(f"\n[configs2] 1080p bf16 vs fp32: PSNR {psnr(a, f32):.2f} dB, PSNR delta at a 30 dB target {psnr_delta_at(a, f32):.4f} dB")
+    assert psnr(a, f32) >= 50.0 and psnr_delta_at(a, f32) <= 0.05
 
 
 def test_configs3_sde_batch8_100_steps():

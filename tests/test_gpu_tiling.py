@@ -39,3 +39,28 @@ def test_tiled_student_matches_tiling_oracle(with_masks):
     # tiling really changes the function (global norms / attention see one window): whole-frame result differs
     whole = model(x.cuda(), z.cuda(), None if m is None else m.cuda())[0]
     assert float((whole - out).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_inplace_windows_equal_the_gather_and_stitch_path(precision):
+    """Kernel-side tiling (stem / mask-resize kernels read each window from the frame, the head kernel writes only the
+    owned core into the output frame) must give exactly what gathering the windows into a batch and stitching the
+    restored windows gives: same kernels, same window data, no copies."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.tiling import TiledRestorer
+    mk = dict(base_channels=16, num_levels=3, blocks_per_level=1, cond_dim=20, num_masks=10, num_degradation_types=5)
+    model = NAFNetWFIGate(**mk, precision=precision)
+    model.load_state_dict(synth_state_dict(student_param_shapes(**mk), seed=12))
+    model = model.cuda().eval()
+    x, z, m = synth_student_inputs(2, 72, 104, 20, 10, mask_hw=(7, 7), seed=78)   # ragged: last cells are clipped
+    restorer = TiledRestorer(model, tile=32, halo=8, max_batch=7)
+    a = restorer(x.cuda(), z.cuda(), m.cuda())
+    model.supports_windows = False
+    try:
+        b = restorer(x.cuda(), z.cuda(), m.cuda())
+    finally:
+        model.supports_windows = True
+    assert a.shape == x.shape and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b)

@@ -568,7 +568,7 @@ extern "C" int uwir_softmax_rows(const float* x, int ldx, int B, int C, const fl
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ src, int B, int M, int hs, int ws,
                                                        float* __restrict__ dst, int ldd, int hd, int wd, float sy,
-                                                       float sx) {
+                                                       float sx, const uwir_window* __restrict__ win, int FH, int FW) {
     size_t total = (size_t)B * hd * wd * M;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int m = (int)(i % M);
@@ -583,9 +583,12 @@ __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__
         int y0 = min((int)fy, hs - 1), x0 = min((int)fx, ws - 1);
         int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
         float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float* s = src + ((size_t)b * M + m) * hs * ws;
-        float v00 = s[(size_t)y0 * ws + x0], v01 = s[(size_t)y0 * ws + x1];
-        float v10 = s[(size_t)y1 * ws + x0], v11 = s[(size_t)y1 * ws + x1];
+        // plain batch: image b is contiguous; windows: image b is the hs x ws window of frame win[b].frame at (y, x)
+        const float* s = win ? src + (((size_t)win[b].frame * M + m) * FH + win[b].y) * FW + win[b].x
+                             : src + ((size_t)b * M + m) * hs * ws;
+        const int rs = win ? FW : ws;
+        float v00 = s[(size_t)y0 * rs + x0], v01 = s[(size_t)y0 * rs + x1];
+        float v10 = s[(size_t)y1 * rs + x0], v11 = s[(size_t)y1 * rs + x1];
         float hy = 1.f - ly, hx = 1.f - lx;
         dst[p * ldd + m] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
     }
@@ -597,8 +600,19 @@ extern "C" int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs
     UWIR_CHECK(B > 0 && M > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && ldd >= M, "bilinear: bad shape");
     size_t total = (size_t)B * hd * wd * M;
     hipLaunchKernelGGL(bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, B, M, hs, ws,
-                       dst, ldd, hd, wd, (float)hs / (float)hd, (float)ws / (float)wd);
+                       dst, ldd, hd, wd, (float)hs / (float)hd, (float)ws / (float)wd, (const uwir_window*)nullptr, 0, 0);
     UWIR_LAUNCH_CHECK("bilinear");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_bilinear_win(const float* frames, int M, int FH, int FW, const uwir_window* win, int nwin, int T,
+                                 float* dst, int ldd, int hd, int wd, uwir_stream_t stream) {
+    UWIR_CHECK(frames && win && dst, "bilinear_win: null pointer");
+    UWIR_CHECK(nwin > 0 && M > 0 && T > 0 && T <= FH && T <= FW && hd > 0 && wd > 0 && ldd >= M, "bilinear_win: bad shape");
+    size_t total = (size_t)nwin * hd * wd * M;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, nwin, M, T, T, dst,
+                       ldd, hd, wd, (float)T / (float)hd, (float)T / (float)wd, win, FH, FW);
+    UWIR_LAUNCH_CHECK("bilinear_win");
     return UWIR_OK;
 }
 
@@ -646,9 +660,15 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, 
 // instructions on 27 scalar + 27 vector loads per 4 outputs (0.9 TB/s on the 268 MB fp32 output of the student stem).
 __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict__ x, int B, int Cin, int H, int W,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                         int Cout, float* __restrict__ out, int ldo) {
+                                                         int Cout, float* __restrict__ out, int ldo,
+                                                         const uwir_window* __restrict__ win, int FH, int FW) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (ox >= W || oy >= H) return;
+    // plain batch: image b is contiguous NCHW; windows: image b is the H x W window of frame win[b].frame at (y, x) --
+    // the conv still pads with zeros at the WINDOW border (every window is an image of its own to the network)
+    const size_t plane = win ? (size_t)FH * FW : (size_t)H * W;
+    const int rs = win ? FW : W;
+    const float* xb = win ? x + ((size_t)win[b].frame * Cin * FH + win[b].y) * FW + win[b].x : x + (size_t)b * Cin * plane;
     float in[36];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -656,7 +676,7 @@ __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict
         const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
-            in[t * 4 + ci] = (ok && ci < Cin) ? x[(((size_t)b * Cin + ci) * H + iy) * W + ix] : 0.f;
+            in[t * 4 + ci] = (ok && ci < Cin) ? xb[ci * plane + (size_t)iy * rs + ix] : 0.f;
     }
     float* o = out + (((size_t)b * H + oy) * W + ox) * ldo;
     for (int c0 = 0; c0 < Cout; c0 += 16) {
@@ -682,7 +702,7 @@ extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int
     UWIR_CHECK(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout % 4 == 0 && ldo >= Cout && ldo % 4 == 0, "stem: bad shape");
     if (Cin <= 4 && Cout % 16 == 0 && B <= 65535 && ceil_div(H, 4) <= 65535) {
         hipLaunchKernelGGL(stem_pixel_kernel, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
-                           x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo);
+                           x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo, (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("stem(pixel)");
         return UWIR_OK;
     }
@@ -690,6 +710,18 @@ extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int
     hipLaunchKernelGGL(stem_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, B, Cin, H, W, w,
                        bias, Cout / 4, out, ldo);
     UWIR_LAUNCH_CHECK("stem");
+    return UWIR_OK;
+}
+
+extern "C" int uwir_stem_conv3x3_win(const float* frames, int Cin, int FH, int FW, const uwir_window* win, int nwin, int T,
+                                     const float* w, const float* bias, int Cout, float* out, int ldo,
+                                     uwir_stream_t stream) {
+    UWIR_CHECK(frames && win && w && out, "stem_win: null pointer");
+    UWIR_CHECK(nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && ldo >= Cout && ldo % 4 == 0, "stem_win: bad shape");
+    UWIR_CHECK(Cin >= 1 && Cin <= 4 && Cout % 16 == 0, "stem_win: needs Cin <= 4 and Cout %% 16 == 0");
+    hipLaunchKernelGGL(stem_pixel_kernel, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream, frames,
+                       nwin, Cin, T, T, w, bias, Cout, out, ldo, win, FH, FW);
+    UWIR_LAUNCH_CHECK("stem_win");
     return UWIR_OK;
 }
 
@@ -772,11 +804,19 @@ __global__ void __launch_bounds__(256) head_tile_kernel(const float* __restrict_
                                                         const float* __restrict__ a_shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int Cout,
                                                         const float* __restrict__ res, float* __restrict__ out,
-                                                        float* __restrict__ preclamp, int Ho, int Wo, int do_clamp) {
+                                                        float* __restrict__ preclamp, int Ho, int Wo, int do_clamp,
+                                                        const uwir_window* __restrict__ win, int FH, int FW) {
     constexpr int PH = HT_H + 2, PW = HT_W + 2, NPIX = PH * PW;
     __shared__ __attribute__((aligned(16))) float tile[NPIX * HT_PS];
     const int tid = threadIdx.x, tx = tid % HT_W, ty = tid / HT_W;
     const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H, b = blockIdx.z;
+    // windows: image b is a window of a frame; only its OWNED core [cy0,cy1) x [cx0,cx1) (frame coordinates) is written,
+    // straight into the output frame, and the residual is read from the input frame.  Tiles without an owned pixel leave.
+    uwir_window wd = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (win) {
+        wd = win[b];
+        if (wd.y + y0 >= wd.cy1 || wd.y + y0 + HT_H <= wd.cy0 || wd.x + x0 >= wd.cx1 || wd.x + x0 + HT_W <= wd.cx0) return;
+    }
     float acc[HEAD_MAX_COUT] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < Cin; c0 += HT_CC) {
         if (c0) __syncthreads();
@@ -818,10 +858,12 @@ __global__ void __launch_bounds__(256) head_tile_kernel(const float* __restrict_
     }
     const int oy = y0 + ty, ox = x0 + tx;
     if (oy >= Ho || ox >= Wo) return;
+    if (win && (wd.y + oy < wd.cy0 || wd.y + oy >= wd.cy1 || wd.x + ox < wd.cx0 || wd.x + ox >= wd.cx1)) return;
 #pragma unroll
     for (int co = 0; co < HEAD_MAX_COUT; ++co) {
         if (co < Cout) {
-            const size_t o = (((size_t)b * Cout + co) * Ho + oy) * Wo + ox;
+            const size_t o = win ? (((size_t)wd.frame * Cout + co) * FH + wd.y + oy) * FW + wd.x + ox
+                                 : (((size_t)b * Cout + co) * Ho + oy) * Wo + ox;
             float v = acc[co] + (bias ? bias[co] : 0.f);
             if (res) v += res[o];
             if (preclamp) preclamp[o] = v;
@@ -845,7 +887,8 @@ extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, i
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head: a_scale/a_shift must come together");
     if (head_tiled_ok(B, H, W, Cin)) {
         hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0, (hipStream_t)stream,
-                           x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw, H, W, 1);
+                           x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw, H, W, 1,
+                           (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("head(tile)");
         return UWIR_OK;
     }
@@ -858,6 +901,22 @@ extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, i
     return UWIR_OK;
 }
 
+extern "C" int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, int Cin, const float* a_scale,
+                                     const float* a_shift, const float* w, const float* bias, int Cout,
+                                     const float* frames_in, float* frames_out, int FH, int FW, const uwir_window* win,
+                                     uwir_stream_t stream) {
+    UWIR_CHECK(x && w && frames_in && frames_out && win, "head_win: null pointer");
+    UWIR_CHECK(nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && Cin % HT_CC == 0 && Cout >= 1 &&
+                   Cout <= HEAD_MAX_COUT && ldx >= Cin && ldx % 4 == 0,
+               "head_win: bad shape (Cin %% 16 == 0, Cout <= %d)", HEAD_MAX_COUT);
+    UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head_win: a_scale/a_shift must come together");
+    hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in, frames_out, (float*)nullptr, T, T, 1, win,
+                       FH, FW);
+    UWIR_LAUNCH_CHECK("head_win");
+    return UWIR_OK;
+}
+
 extern "C" int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                                  int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
     UWIR_CHECK(x && w && out_nchw, "tail: null pointer");
@@ -867,7 +926,7 @@ extern "C" int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, i
     if (head_tiled_ok(B, Ho, Wo, Cin)) {
         hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0, (hipStream_t)stream,
                            x, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr, w, bias, Cout,
-                           (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0);
+                           (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0, (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("tail(tile)");
         return UWIR_OK;
     }

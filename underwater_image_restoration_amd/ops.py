@@ -298,6 +298,36 @@ def head_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, a_scale, a_s
                                      _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream(x)), "head_conv3x3")
 
 
+def stem_conv3x3_win(frames: torch.Tensor, win: torch.Tensor, T: int, w, bias, out: torch.Tensor) -> None:
+    """Stem conv over the T x T windows `win` (int32 [nwin, 8] device descriptors, see uwir_window) of NCHW frames."""
+    _f32(frames, w, bias, out)
+    if frames.dim() != 4 or not frames.is_contiguous() or win.dtype != torch.int32 or not win.is_contiguous() or win.shape[1] != 8:
+        raise ValueError("stem_conv3x3_win: frames must be contiguous NCHW, win an int32 [nwin, 8] tensor")
+    _, Cin, FH, FW = frames.shape
+    _lib.check(_lib.load().uwir_stem_conv3x3_win(_p(frames), Cin, FH, FW, _p(win), win.shape[0], T, _p(w), _p(bias), w.shape[-1],
+                                                 _p(out), _ld(out), _stream(frames)), "stem_conv3x3_win")
+
+
+def bilinear_win(frames: torch.Tensor, win: torch.Tensor, T: int, dst: torch.Tensor, hd: int, wd: int) -> None:
+    _f32(frames, dst)
+    if frames.dim() != 4 or not frames.is_contiguous() or win.dtype != torch.int32 or not win.is_contiguous():
+        raise ValueError("bilinear_win: frames must be contiguous NCHW, win an int32 [nwin, 8] tensor")
+    _, M, FH, FW = frames.shape
+    _lib.check(_lib.load().uwir_bilinear_win(_p(frames), M, FH, FW, _p(win), win.shape[0], T, _p(dst), _ld(dst), hd, wd,
+                                             _stream(frames)), "bilinear_win")
+
+
+def head_conv3x3_win(x: torch.Tensor, T: int, Cin: int, a_scale, a_shift, w, bias, Cout: int, frames_in: torch.Tensor,
+                     frames_out: torch.Tensor, win: torch.Tensor) -> None:
+    _f32(x, a_scale, a_shift, w, bias, frames_in, frames_out)
+    if frames_in.shape != frames_out.shape or not frames_in.is_contiguous() or not frames_out.is_contiguous():
+        raise ValueError("head_conv3x3_win: frames must be contiguous NCHW tensors of one shape")
+    _, _, FH, FW = frames_in.shape
+    _lib.check(_lib.load().uwir_head_conv3x3_win(_p(x), _ld(x), win.shape[0], T, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias),
+                                                 Cout, _p(frames_in), _p(frames_out), FH, FW, _p(win), _stream(x)),
+               "head_conv3x3_win")
+
+
 def sde_euler_step(x, mu, noise, eps, x_out, theta: float, sigma: float, sigma_bar: float, dt: float,
                    score_weight: float = 1.0) -> None:
     _f32(x, mu, noise, eps, x_out)

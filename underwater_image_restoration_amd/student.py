@@ -69,6 +69,7 @@ class NAFNetWFIGate(nn.Module):
         self._streams: dict = {}            # device -> side stream of the SFFB branch
         self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
+        self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self) -> None:
@@ -392,8 +393,12 @@ class NAFNetWFIGate(nn.Module):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @ops.on_operand_device
-    def forward(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None, taps: Optional[dict] = None
-                ) -> Tuple[torch.Tensor, List[torch.Tensor], Optional[torch.Tensor]]:
+    def forward(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
+                windows: Optional[dict] = None) -> Tuple[torch.Tensor, List[torch.Tensor], Optional[torch.Tensor]]:
+        """``windows`` (halo tiling, tiling.TiledRestorer; no reference counterpart): dict(win=int32 [nwin, 8] device
+        descriptors (uwir_window), T=window edge, out=output frames).  Then ``x`` / ``masks`` are whole NCHW FRAMES, the
+        batch the network sees is the nwin windows read in place by the stem / mask-resize kernels, ``cond`` has one row
+        per window, and the head writes every window's owned core straight into ``windows["out"]`` (returned)."""
         if cond is None:
             raise ValueError("Condition vector z_d must be provided.")
         if not x.is_cuda:
@@ -401,6 +406,16 @@ class NAFNetWFIGate(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError("Input must be (B, in_channels, H, W).")
         B, _, H, W = x.shape
+        win = None
+        if windows is not None:
+            win, T = windows["win"], int(windows["T"])
+            if masks is not None and tuple(masks.shape[-2:]) != (H, W):
+                raise ValueError("window mode: masks must be frame sized (B, M, H, W)")
+            if windows["out"].shape != x.shape or taps is not None:
+                raise ValueError("window mode: out must have the frames' shape; taps are not available")
+            B, H, W = int(win.shape[0]), T, T
+            if cond.shape[0] != B:
+                raise ValueError("window mode: cond needs one row per window")
         div = 2 ** self.num_levels
         if H % div or W % div:
             raise ValueError(f"H and W must be multiples of {div} for this build (got {H}x{W})")
@@ -427,13 +442,18 @@ class NAFNetWFIGate(nn.Module):
             Hl, Wl = H >> lvl, W >> lvl
             h, w = Hl // 2, Wl // 2
             gi = self._buf(f"gate_in{lvl}", B * h * w, 2 * ch[lvl] + Mp, f32, dev, zero=True)
-            if masks is not None:
+            if masks is not None and win is not None:
+                ops.bilinear_win(masks, win, H, gi[:, 2 * ch[lvl]:2 * ch[lvl] + Mk], h, w)
+            elif masks is not None:
                 ops.bilinear_nchw_to_nhwc(masks, gi[:, 2 * ch[lvl]:2 * ch[lvl] + Mk], h, w)
             gate_in.append(gi)
             feat.append([self._buf(f"feat{lvl}_{i}", B * Hl * Wl, ch[lvl], f32, dev) for i in range(2)])
             cat.append(self._buf(f"cat{lvl}", B * Hl * Wl, 2 * ch[lvl], f32, dev) if lvl < L - 1 else None)
 
-        ops.stem_conv3x3(x, pk["stem_w"], pk["stem_b"], feat[0][0])
+        if win is not None:
+            ops.stem_conv3x3_win(x, win, H, pk["stem_w"], pk["stem_b"], feat[0][0])
+        else:
+            ops.stem_conv3x3(x, pk["stem_w"], pk["stem_b"], feat[0][0])
         if taps is not None:
             taps["stem"] = feat[0][0].reshape(B, H, W, ch[0]).permute(0, 3, 1, 2).clone()
         alphas: List[torch.Tensor] = []
@@ -489,12 +509,15 @@ class NAFNetWFIGate(nn.Module):
         fa, fs = self._buf("fn_a", B, ch[0], f32, dev), self._buf("fn_s", B, ch[0], f32, dev)
         ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, H * W, ch[0]) // 8, 1), torch.float64, dev)
         ops.ln2d_affine(cur, B, H * W, ch[0], _EPS, pk["fn_g"], pk["fn_b"], None, fa, fs, None, None, ws)
+        if self.in_channels != self.out_channels:
+            raise ValueError("in_channels must equal out_channels (the head adds the input residual, model.py:161)")
+        if win is not None:
+            out = windows["out"]
+            ops.head_conv3x3_win(cur, H, ch[0], fa, fs, pk["head_w"], pk["head_b"], self.out_channels, x, out, win)
+            return out, alphas, logits
         out = torch.empty(B, self.out_channels, H, W, dtype=f32, device=dev)
         pre = torch.empty_like(out) if taps is not None else None
-        res = x if self.in_channels == self.out_channels else None
-        if res is None:
-            raise ValueError("in_channels must equal out_channels (the head adds the input residual, model.py:161)")
-        ops.head_conv3x3(cur, B, H, W, ch[0], fa, fs, pk["head_w"], pk["head_b"], self.out_channels, res, out, pre)
+        ops.head_conv3x3(cur, B, H, W, ch[0], fa, fs, pk["head_w"], pk["head_b"], self.out_channels, x, out, pre)
         if taps is not None:
             taps["pre_clamp"] = pre
         return out, alphas, logits

@@ -73,7 +73,7 @@ class TiledRestorer:
         B, M = masks.shape[:2]
         rows = torch.empty(B * H * W, M, dtype=torch.float32, device=masks.device)
         ops.bilinear_nchw_to_nhwc(masks.contiguous().float(), rows, H, W)
-        return rows.view(B, H, W, M).permute(0, 3, 1, 2)
+        return rows.view(B, H, W, M).permute(0, 3, 1, 2).contiguous()   # NCHW frames: the window kernels index planes
 
     @torch.no_grad()
     def run_windows(self, x, cond, fmasks, tiles: List[Tile]) -> torch.Tensor:
@@ -101,6 +101,30 @@ class TiledRestorer:
             out[:, :, t.cy0:t.cy1, t.cx0:t.cx1] = win[:, i, :, t.cy0 - t.wy:t.cy1 - t.wy, t.cx0 - t.wx:t.cx1 - t.wx]
         return out
 
+    def window_descriptors(self, n_frames: int, tiles: List[Tile], device) -> torch.Tensor:
+        """int32 [n_frames * len(tiles), 8] device array of ``uwir_window`` records (frame-major), cached per plan."""
+        key = (n_frames, tuple(tiles), str(device))
+        cache = self.__dict__.setdefault("_desc_cache", {})
+        d = cache.get(key)
+        if d is None:
+            rows = [[f, t.wy, t.wx, t.cy0, t.cy1, t.cx0, t.cx1, 0] for f in range(n_frames) for t in tiles]
+            d = torch.tensor(rows, dtype=torch.int32).to(device)
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = d
+        return d
+
+    @torch.no_grad()
+    def restore_windows_inplace(self, x, cond, fmasks, desc: torch.Tensor, out: torch.Tensor) -> None:
+        """Kernel-side tiling: the windows ``desc`` are read in place from the frames ``x`` (and the frame-sized masks)
+        by the stem / mask-resize kernels and their owned cores are written straight into ``out`` by the head kernel."""
+        x = x.contiguous().float()
+        fmasks = None if fmasks is None else fmasks.contiguous().float()
+        for s in range(0, desc.shape[0], self.max_batch):
+            d = desc[s:s + self.max_batch]
+            cw = cond.index_select(0, d[:, 0].long())           # the frame's z_d for each of its windows
+            self.model(x, cw, fmasks, windows=dict(win=d, T=self.tile, out=out))
+
     @torch.no_grad()
     @ops.on_operand_device
     def __call__(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -113,4 +137,9 @@ class TiledRestorer:
         if tiles is None:
             return self.model(x, cond, masks)[0]
         fm = self.frame_masks(masks, H, W)
-        return self.stitch(self.run_windows(x, cond, fm, tiles), tiles, H, W)
+        if getattr(self.model, "supports_windows", False) and x.is_cuda:
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)   # every pixel is owned by exactly one window
+            self.restore_windows_inplace(x, cond, None if fm is None else fm.contiguous(), self.window_descriptors(
+                x.shape[0], tiles, x.device), out)
+            return out
+        return self.stitch(self.run_windows(x, cond, fm, tiles), tiles, H, W)   # generic callables: gather / stitch copies
