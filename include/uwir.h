@@ -36,6 +36,12 @@ int uwir_version(void);
 /* Measurement switch with no counterpart in the reference: selects the 3x3 halo-conv tile shape (0 = 8-row tiles, the
  * default; 1 = 16-row tiles) so tools/bench_conv3x3.py can A/B them in one process.  Results are identical either way. */
 void uwir_conv_variant(int variant);
+/* Test / measurement switch, no counterpart in the reference: tiles walked by one block of the pipelined depthwise
+ * kernel (0 = chosen from the grid size, the default).  Results are identical for every value. */
+void uwir_dwconv_tiles_per_block(int nt);
+/* Measurement switch, no counterpart in the reference: where the packed-stream attention kernel sums its softmax
+ * denominators when the V^T tile has no spare row (-1 = per-shape default, 0 = ones-operand MFMA, 1 = packed fp32 adds). */
+void uwir_attn_variant(int lsv);
 const char* uwir_last_error(void);
 
 /* ---- S/dwt_fft.py:33-39 dwt2 -------------------------------------------------------------

@@ -296,6 +296,41 @@ def test_dwconv_ms(ops, io, shape):
         assert rel(from_rows(out, b, h, w), ref) < (1e-5 if odt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("io", [("fp32", "bf16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("nt", [1, 2, 3, 5])
+def test_dwconv_ms_pipelined_tiles(ops, io, nt):
+    """The wave-per-quad kernel walks nt tiles per block with the next tile's halo prefetched (bf16 input: loader /
+    storer wave roles): every nt, ragged tile counts and clipped edge tiles must give the one-tile result bit for bit."""
+    from underwater_image_restoration_amd import _lib
+    lib = _lib.load()
+    b, c, h, w = 2, 64, 70, 53   # 5 x 4 tiles, clipped on both edges; 20 tiles is not a multiple of 3
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(b, c, h, w, generator=g)
+    ws = [torch.randn(c, 1, k, k, generator=g) / k for k in (3, 5, 7)]
+    bs = [torch.randn(c, generator=g) for _ in range(3)]
+    asc, ash = torch.rand(b, c, generator=g) + 0.5, torch.randn(b, c, generator=g)
+    idt = torch.bfloat16 if io[0] == "bf16" else torch.float32
+    xin = to_rows(x).to(idt)
+    xe = xin.float().cpu().reshape(b, h, w, c).permute(0, 3, 1, 2).double()
+    taps = tuple(wk.reshape(c, -1).t().contiguous().cuda() for wk in ws)
+    for use_aff in (False, True):
+        xa = xe * asc.double()[:, :, None, None] + ash.double()[:, :, None, None] if use_aff else xe
+        ref = torch.cat([F.conv2d(xa, wk.double(), bk.double(), padding=wk.shape[-1] // 2, groups=c) for wk, bk in zip(ws, bs)], 1)
+        outs = []
+        for n in (1, nt):
+            lib.uwir_dwconv_tiles_per_block(n)
+            try:
+                out = torch.full((b * h * w, 3 * c), float("nan"), device="cuda", dtype=torch.bfloat16)
+                ops.dwconv_ms(xin, b, h, w, c, taps, tuple(t.cuda() for t in bs), out,
+                              in_scale=asc.cuda() if use_aff else None, in_shift=ash.cuda() if use_aff else None)
+                torch.cuda.synchronize()
+            finally:
+                lib.uwir_dwconv_tiles_per_block(0)
+            outs.append(out)
+        assert rel(from_rows(outs[0], b, h, w), ref) < 1e-2
+        assert torch.equal(outs[0], outs[1])
+
+
 def _attn_ref(q, k, vs, heads, hd):
     b, n, _ = q.shape
     qh = q.reshape(b, n, heads, hd).permute(0, 2, 1, 3)

@@ -1,140 +1,9 @@
-// Multi-scale depthwise convolution 3x3 + 5x5 + 7x7 (zero padding) fused with the channel concat
-// that feeds the 1x1 merge conv (S/wtb.py:53-62,91; S/sffb.py:21-31,46).
-//
-// NHWC.  A block owns an 8x16 pixel tile x 32-channel slab: the (8+6)x(16+6) halo tile is staged
-// once in LDS as fp32 (input affine = normalise-on-load applied here; out-of-image pixels are 0,
-// i.e. padding happens AFTER the norm like the reference), the 83 taps x 32 channels of weights
-// sit beside it.  A thread produces 4 consecutive x pixels of one channel quad for all three
-// kernel sizes from a sliding 10-wide register row, so every staged value is read from LDS once
-// per row and feeds up to 15 taps x 4 pixels.
+// Experiment: where does dwconv_ms32 spend its time?  MODE bit0: no global loads in staging, bit1: one filter row
+// instead of seven, bit2: no output stores.   python tools/exp/make_dw_phases.py regenerates this file from csrc/dwconv.hip
 #include "common.h"
-
-#define DW_TH 8
-#define DW_TW 16
-#define DW_CS 32                       // channels per block
+#include <cstdio>
+#include <cstdlib>
 #define DW_HALO 3
-#define DW_LW (DW_TW + 2 * DW_HALO)    // 22
-#define DW_LH (DW_TH + 2 * DW_HALO)    // 14
-#define DW_ROWSTRIDE (DW_LW * DW_CS + 32)  // floats; +32 makes consecutive rows hit opposite bank halves
-#define DW_NTAPS (9 + 25 + 49)
-
-template <typename TIN, typename TOUT>
-__global__ void __launch_bounds__(256) dwconv_ms_kernel(const TIN* __restrict__ x, int ldx, int H, int W, int C,
-                                                        const float* __restrict__ in_scale,
-                                                        const float* __restrict__ in_shift,
-                                                        const float* __restrict__ w3, const float* __restrict__ w5,
-                                                        const float* __restrict__ w7, const float* __restrict__ b3,
-                                                        const float* __restrict__ b5, const float* __restrict__ b7,
-                                                        TOUT* __restrict__ out, int ldo, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) float s_in[DW_LH * DW_ROWSTRIDE];
-    __shared__ __attribute__((aligned(16))) float s_w[DW_NTAPS * DW_CS];
-
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * DW_CS;
-    const int ty0 = (blockIdx.x / tiles_x) * DW_TH, tx0 = (blockIdx.x % tiles_x) * DW_TW;
-    const int nq = min(DW_CS, C - c0) / 4;  // valid quads in this slab
-
-    // ---- stage weights: s_w[tap][32], taps ordered [3x3 | 5x5 | 7x7]
-    for (int i = tid; i < DW_NTAPS * (DW_CS / 4); i += 256) {
-        int tap = i / (DW_CS / 4), q = i % (DW_CS / 4);
-        float4 v = make_float4(0, 0, 0, 0);
-        if (q < nq) {
-            const float* src = tap < 9 ? w3 + (size_t)tap * C : (tap < 34 ? w5 + (size_t)(tap - 9) * C : w7 + (size_t)(tap - 34) * C);
-            v = load4(src + c0 + 4 * q);
-        }
-        *reinterpret_cast<float4*>(&s_w[tap * DW_CS + 4 * q]) = v;
-    }
-    // ---- stage halo tile
-    for (int i = tid; i < DW_LH * DW_LW * (DW_CS / 4); i += 256) {
-        int q = i % (DW_CS / 4);
-        int p = i / (DW_CS / 4);
-        int lx = p % DW_LW, ly = p / DW_LW;
-        int iy = ty0 + ly - DW_HALO, ix = tx0 + lx - DW_HALO;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (q < nq && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            v = load4(x + (((size_t)b * H + iy) * W + ix) * ldx + c0 + 4 * q);
-            if (in_scale) {
-                float4 sc = load4(in_scale + (size_t)b * C + c0 + 4 * q);
-                float4 sh = load4(in_shift + (size_t)b * C + c0 + 4 * q);
-                v.x = fmaf(v.x, sc.x, sh.x);
-                v.y = fmaf(v.y, sc.y, sh.y);
-                v.z = fmaf(v.z, sc.z, sh.z);
-                v.w = fmaf(v.w, sc.w, sh.w);
-            }
-        }
-        *reinterpret_cast<float4*>(&s_in[ly * DW_ROWSTRIDE + lx * DW_CS + 4 * q]) = v;
-    }
-    __syncthreads();
-
-    const int q = tid % 8, y = (tid / 8) % 8, xg = tid / 64;  // 8 quads x 8 rows x 4 x-groups
-    if (q >= nq) return;
-    float4 a3[4], a5[4], a7[4];
-    {
-        float4 z = make_float4(0, 0, 0, 0);
-        float4 v3 = b3 ? load4(b3 + c0 + 4 * q) : z, v5 = b5 ? load4(b5 + c0 + 4 * q) : z,
-               v7 = b7 ? load4(b7 + c0 + 4 * q) : z;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a3[j] = v3; a5[j] = v5; a7[j] = v7; }
-    }
-#define FMA4(acc, wv, iv)                 \
-    acc.x = fmaf(wv.x, iv.x, acc.x);      \
-    acc.y = fmaf(wv.y, iv.y, acc.y);      \
-    acc.z = fmaf(wv.z, iv.z, acc.z);      \
-    acc.w = fmaf(wv.w, iv.w, acc.w);
-#pragma unroll 1
-    for (int ky = 0; ky < 7; ++ky) {
-        float4 row[10];
-        const float* rp = &s_in[(y + ky) * DW_ROWSTRIDE + (xg * 4) * DW_CS + 4 * q];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) row[i] = *reinterpret_cast<const float4*>(rp + i * DW_CS);
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            float4 wv = *reinterpret_cast<const float4*>(&s_w[(34 + ky * 7 + kx) * DW_CS + 4 * q]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { FMA4(a7[j], wv, row[j + kx]) }
-        }
-        if (ky >= 1 && ky <= 5) {
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                float4 wv = *reinterpret_cast<const float4*>(&s_w[(9 + (ky - 1) * 5 + kx) * DW_CS + 4 * q]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { FMA4(a5[j], wv, row[j + kx + 1]) }
-            }
-        }
-        if (ky >= 2 && ky <= 4) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float4 wv = *reinterpret_cast<const float4*>(&s_w[((ky - 2) * 3 + kx) * DW_CS + 4 * q]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { FMA4(a3[j], wv, row[j + kx + 2]) }
-            }
-        }
-    }
-#undef FMA4
-    const int oy = ty0 + y;
-    if (oy >= H) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int ox = tx0 + xg * 4 + j;
-        if (ox < W) {
-            TOUT* o = out + (((size_t)b * H + oy) * W + ox) * ldo + c0 + 4 * q;
-            store4(o, a3[j]);
-            store4(o + C, a5[j]);
-            store4(o + 2 * C, a7[j]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Second form (C % 32 == 0): the kernel above reads 83 weight quads + 70 input quads from LDS per thread and is bound
-// by LDS bandwidth, not by its FMAs.  Here a WAVE owns one channel quad, so the 83 x 4 weights of the quad are
-// wave-uniform and arrive through scalar loads (SGPR operands of the packed FMAs): LDS carries the input rows only.
-// Block = 8 waves = 32 channels over a 16 x 16 pixel tile; lane = (row y, 4-pixel group xg); the 22 x 22 halo tile sits
-// in LDS as one fp32 plane per quad with an odd row pitch (23 quads), which makes the 16 row-lanes of a 16-byte LDS
-// read hit 16 distinct bank groups.  A lane's results are 8-byte pieces scattered over 12 (pixel, scale) rows, so bf16
-// outputs are transposed through LDS (the halo tile's storage, reused) and leave as 64-byte runs per (pixel, scale).
-// ------------------------------------------------------------------------------------------
 #define D2_T 16
 #define D2_L (D2_T + 2 * DW_HALO)   // 22
 #define D2_PITCH 23                 // quads per LDS row (odd)
@@ -186,7 +55,7 @@ __device__ __forceinline__ int opaque_s(int v) {   // same for a wave-uniform va
     return v;
 }
 
-template <typename TIN, typename TOUT, bool AFF>
+template <typename TIN, typename TOUT, bool AFF, int MODE>
 __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restrict__ x, int ldx, int H, int W, int C,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
@@ -234,7 +103,7 @@ __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restri
             int ly, lx, iy, ix;
             const bool ok = item_ok(tid_o, it, ty0, tx0, ly, lx, iy, ix) && live;
             const int off = ((iy * W + ix) * ldx + c0 + 4 * q) * (int)sizeof(TIN);
-            raw[it] = R::load(xrs, ok ? off : DW_OOB);
+            raw[it] = R::load(xrs, (ok && !(MODE & 1)) ? off : DW_OOB);
         }
     };
     float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
@@ -291,7 +160,7 @@ __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restri
     acc.z = fmaf(wv.z, iv.z, acc.z);      \
     acc.w = fmaf(wv.w, iv.w, acc.w);
 #pragma unroll 1
-        for (int ky = 0; ky < 7; ++ky) {
+        for (int ky = 0; ky < ((MODE & 2) ? 1 : 7); ++ky) {
             float4 row[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) row[i] = plane[ky * D2_PITCH + i];
@@ -332,9 +201,7 @@ __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restri
         __syncthreads();
         if (storer) {
             // 16-byte pieces, 4 per (pixel, scale): piece = i & 3, pixel = (i >> 2) % 256, scale = i >> 10, so a store
-            // instruction covers 16 whole 64-byte runs and everything but the thread's base offsets is a constant.
-            // (Pulling the whole staged tile into registers first, to release the staging area before the first store
-            // is issued, needs 96 registers next to the loaders' prefetch and spills.)
+            // instruction covers 16 whole 64-byte runs and everything but the thread's base offsets is a constant
             const int ty0 = (t / tiles_x) * D2_T, tx0 = (t % tiles_x) * D2_T;
             const int ts = opaque(tid) & (NST - 1);
             const int piece = ts & 3, px = (ts >> 2) & 15, py0 = ts >> 6;
@@ -345,7 +212,7 @@ __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restri
 #pragma unroll
             for (int r = 0; r < RPS; ++r) {
                 const int oy = ty0 + py0 + (NST / 64) * r;
-                const int voff = (oy < H && ox < W) ? off0 + (NST / 64) * r * W * ldo * 2 : DW_OOB;
+                const int voff = (oy < H && ox < W && !(MODE & 4)) ? off0 + (NST / 64) * r * W * ldo * 2 : DW_OOB;
 #pragma unroll
                 for (int scl = 0; scl < 3; ++scl) {
                     const dw_u32x4 v = *reinterpret_cast<const dw_u32x4*>(src + (NST / 64) * r * D2_OPS + scl * 32);
@@ -357,57 +224,33 @@ __global__ void __launch_bounds__(512, 4) dwconv_ms32_kernel(const TIN* __restri
     }
 }
 
-static int g_dw_nt = 0;   // 0: choose by grid size
-extern "C" void uwir_dwconv_tiles_per_block(int nt) { g_dw_nt = nt < 0 ? 0 : (nt > 64 ? 64 : nt); }
 
-template <typename TIN, typename TOUT>
-static int launch_dw(const void* x, int ldx, int B, int H, int W, int C, const float* in_scale, const float* in_shift,
-                     const float* w3, const float* w5, const float* w7, const float* b3, const float* b5,
-                     const float* b7, void* out, int ldo, hipStream_t stream) {
-    // bf16 outputs with 16-byte-aligned rows take the wave-per-quad kernel
-    if constexpr (sizeof(TOUT) == 2) {
-      if (C % 32 == 0 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0 &&
-        (long long)ceil_div(W, D2_T) * ceil_div(H, D2_T) <= 65535 &&
-        (size_t)H * W * ldx * sizeof(TIN) < 0x7fffffffULL && (size_t)H * W * ldo * sizeof(TOUT) < 0x7fffffffULL) {
-        const int tx = ceil_div(W, D2_T), ty = ceil_div(H, D2_T), tiles = tx * ty;
-        // tiles per block: enough blocks left for >= 8 rounds of the chip's 512 resident blocks
-        const long long nblk = (long long)(C / 32) * tiles * B;
-        const int nt = g_dw_nt ? g_dw_nt : (nblk >= 16384 ? 4 : (nblk >= 8192 ? 3 : (nblk >= 2048 ? 2 : 1)));
-        const dim3 grid(C / 32, ceil_div(tiles, nt), B);
-        if (in_scale)
-            hipLaunchKernelGGL((dwconv_ms32_kernel<TIN, TOUT, true>), grid, dim3(512), 0, stream, (const TIN*)x, ldx, H, W, C,
-                               in_scale, in_shift, w3, w5, w7, b3, b5, b7, (TOUT*)out, ldo, tx, tiles, nt);
-        else
-            hipLaunchKernelGGL((dwconv_ms32_kernel<TIN, TOUT, false>), grid, dim3(512), 0, stream, (const TIN*)x, ldx, H, W, C,
-                               in_scale, in_shift, w3, w5, w7, b3, b5, b7, (TOUT*)out, ldo, tx, tiles, nt);
-        UWIR_LAUNCH_CHECK("dwconv_ms(32)");
-        return UWIR_OK;
-      }
-    }
-    int tiles_x = ceil_div(W, DW_TW), tiles_y = ceil_div(H, DW_TH);
-    dim3 grid(tiles_x * tiles_y, ceil_div(C, DW_CS), B);
-    hipLaunchKernelGGL((dwconv_ms_kernel<TIN, TOUT>), grid, dim3(256), 0, stream, (const TIN*)x, ldx, H, W, C, in_scale,
-                       in_shift, w3, w5, w7, b3, b5, b7, (TOUT*)out, ldo, tiles_x);
-    UWIR_LAUNCH_CHECK("dwconv_ms");
-    return UWIR_OK;
+template <int MODE> static float run(const bf16_t* x, bf16_t* out, const float* w, int B, int H, int W, int C, int nt) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int tx = (W + 15) / 16, ty = (H + 15) / 16, tiles = tx * ty;
+    auto go = [&]() { hipLaunchKernelGGL((dwconv_ms32_kernel<bf16_t, bf16_t, false, MODE>), dim3(C / 32, (tiles + nt - 1) / nt, B), dim3(512), 0, 0, x, C, H, W, C,
+        (const float*)nullptr, (const float*)nullptr, w, w + 9 * C, w + 34 * C, w + 83 * C, w + 84 * C, w + 85 * C, out, 3 * C, tx, tiles, nt); };
+    go(); go(); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms / 10;
 }
-
-extern "C" int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int C, const float* in_scale,
-                              const float* in_shift, const float* w3, const float* w5, const float* w7,
-                              const float* b3, const float* b5, const float* b7, void* out, int out_dtype, int ldo,
-                              uwir_stream_t stream) {
-    UWIR_CHECK(x && out && w3 && w5 && w7, "dwconv_ms: null pointer");
-    UWIR_CHECK(B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv_ms: bad shape");
-    UWIR_CHECK(ldx >= C && ldx % 4 == 0 && ldo >= 3 * C && ldo % 4 == 0, "dwconv_ms: bad strides");
-    UWIR_CHECK((in_scale == nullptr) == (in_shift == nullptr), "dwconv_ms: in_scale/in_shift must come together");
-    hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == UWIR_F32 && out_dtype == UWIR_F32)
-        return launch_dw<float, float>(x, ldx, B, H, W, C, in_scale, in_shift, w3, w5, w7, b3, b5, b7, out, ldo, s);
-    if (x_dtype == UWIR_F32 && out_dtype == UWIR_BF16)
-        return launch_dw<float, bf16_t>(x, ldx, B, H, W, C, in_scale, in_shift, w3, w5, w7, b3, b5, b7, out, ldo, s);
-    if (x_dtype == UWIR_BF16 && out_dtype == UWIR_BF16)
-        return launch_dw<bf16_t, bf16_t>(x, ldx, B, H, W, C, in_scale, in_shift, w3, w5, w7, b3, b5, b7, out, ldo, s);
-    if (x_dtype == UWIR_BF16 && out_dtype == UWIR_F32)
-        return launch_dw<bf16_t, float>(x, ldx, B, H, W, C, in_scale, in_shift, w3, w5, w7, b3, b5, b7, out, ldo, s);
-    return uwir_set_error(UWIR_EUNSUPPORTED, "dwconv_ms: unsupported dtype combination");
+int main(int argc, char** argv) {
+    const int B = 16, H = 128, W = 128, C = 576;
+    size_t nx = (size_t)B * H * W * C;
+    bf16_t *x, *out; float* w;
+    (void)hipMalloc(&x, nx * 2); (void)hipMalloc(&out, nx * 6); (void)hipMalloc(&w, 86 * C * 4);
+    (void)hipMemset(x, 0, nx * 2); (void)hipMemset(w, 0, 86 * C * 4);
+    for (int a = 1; a < (argc > 1 ? argc : 2); ++a) {
+        const int nt = argc > 1 ? atoi(argv[a]) : 4;
+        printf("tiles per block %d\n", nt);
+        printf("  full            %.3f ms\n", run<0>(x, out, w, B, H, W, C, nt));
+        printf("  no loads        %.3f ms\n", run<1>(x, out, w, B, H, W, C, nt));
+        printf("  1/7 compute     %.3f ms\n", run<2>(x, out, w, B, H, W, C, nt));
+        printf("  no stores       %.3f ms\n", run<4>(x, out, w, B, H, W, C, nt));
+        printf("  loads only      %.3f ms\n", run<6>(x, out, w, B, H, W, C, nt));
+        printf("  compute only    %.3f ms\n", run<5>(x, out, w, B, H, W, C, nt));
+        printf("  stores only     %.3f ms\n", run<3>(x, out, w, B, H, W, C, nt));
+        printf("  nothing         %.3f ms\n", run<7>(x, out, w, B, H, W, C, nt));
+    }
+    return 0;
 }

@@ -97,6 +97,8 @@ _SIGS = {
     "uwir_linattn_block_workspace_bytes": (sz, [ci, ci]),
     "uwir_linattn_block": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, ci, vp, sz, vp]),
     "uwir_conv_variant": (None, [ci]),
+    "uwir_dwconv_tiles_per_block": (None, [ci]),
+    "uwir_attn_variant": (None, [ci]),
     "uwir_geglu": (ci, [vp, ci, sz, ci, ci, vp, sz, vp]),
     "uwir_softmax_rows": (ci, [vp, ci, ci, ci, vp, vp, ci, vp]),
     "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),

@@ -595,7 +595,15 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
     if ((tid & 63) == 0 && m > 0.f) atomicMax(kmax2 + bh, __float_as_uint(m));
 }
 
-template <int HD, int NV, int QG, int PF>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Denominators when the V^T tile has no spare row for a ones row (LSV): 0 = a ones-operand 32x32x16 MFMA per 16 keys
+// (every one of its 32 output rows is the same sum: 64 MFMA cycles per 32 x 32 block); 1 = packed fp32 adds of the
+// exponentials on the VALU (8 per block, on the pipe that bounds this kernel); 2 = a 16x16x32 MFMA whose A operand is
+// a 0/1 selector: fed the 32x32x16 B fragment as it is, lane group G of its k dimension holds queries 16 (G & 1) + n,
+// key half G >> 1, so row 0 = groups {0, 2} and row 1 = groups {1, 3} give the sums of queries n and n + 16: half the
+// MFMA cycles of (0) and no VALU work.
+template <int HD, int NV, int QG, int PF, int LSV>
 __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t* __restrict__ Kp,
                                                           const bf16_t* __restrict__ Vtp, int npad, int nqb, int nblocks) {
     using P = PackCfg<HD, NV>;
@@ -678,6 +686,14 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
     };
 
     f32x16 O[QG][DG], Lacc[QG];
+    f32x2 lsum[QG];
+    f32x4 Lsel[QG];
+    bf16x8 sel;   // row 0 of A lives in lanes 0 / 32 (groups 0, 2), row 1 in lanes 17 / 49 (groups 1, 3)
+    {
+        const bf16_t sv = (bf16_t)((lane == 0 || lane == 32 || lane == 17 || lane == 49) ? 1.f : 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sel[j] = sv;
+    }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
 #pragma unroll
@@ -686,6 +702,8 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
             for (int r = 0; r < 16; ++r) O[g][dg][r] = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Lacc[g][r] = 0.f;
+        lsum[g] = f32x2{0.f, 0.f};
+        Lsel[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     bf16x8 ones;
 #pragma unroll
@@ -710,7 +728,12 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[g][ss][j] = (bf16_t)__builtin_amdgcn_exp2f(s[g][8 * ss + j]);
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 e = {__builtin_amdgcn_exp2f(s[g][8 * ss + j]), __builtin_amdgcn_exp2f(s[g][8 * ss + j + 1])};
+                    if constexpr (LSV == 1 && !SUMROW) lsum[g] += e;
+                    pb[g][ss][j] = (bf16_t)e[0];
+                    pb[g][ss][j + 1] = (bf16_t)e[1];
+                }
         }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
@@ -721,10 +744,15 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
                 for (int g = 0; g < QG; ++g)
                     O[g][dg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pb[g][ss], O[g][dg], 0, 0, 0);
             }
-            if constexpr (!SUMROW) {
+            if constexpr (!SUMROW && LSV == 0) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g)
                     Lacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[g][ss], Lacc[g], 0, 0, 0);
+            }
+            if constexpr (!SUMROW && LSV == 2) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    Lsel[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pb[g][ss], Lsel[g], 0, 0, 0);
             }
         }
     };
@@ -764,6 +792,13 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
             unsigned u = __float_as_uint(O[g][DG - 1][rl]);
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             l = __uint_as_float(sw[hl]);
+        } else if constexpr (LSV == 2) {   // lane n < 16 holds the sums of queries n (row 0) and n + 16 (row 1)
+            const float l0 = __shfl(Lsel[g][0], lq & 15), l1 = __shfl(Lsel[g][1], lq & 15);
+            l = (lq < 16 ? l0 : l1) - (float)(npad - n);
+        } else if constexpr (LSV == 1) {   // this lane's keys, then the other half-wave's (same query, the other 16 of 32)
+            unsigned u = __float_as_uint(lsum[g][0] + lsum[g][1]);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) - (float)(npad - n);
         } else {
             l = Lacc[g][0] - (float)(npad - n);
         }
@@ -818,6 +853,9 @@ static inline void probe_mark(int which, hipStream_t stream) {
     }
 }
 
+static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel), bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V
+extern "C" void uwir_attn_variant(int lsv) { g_attn_lsv = lsv; }
+
 template <int HD, int NV, int QG, int PF>
 static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_t stream) {
     using P = PackCfg<HD, NV>;
@@ -836,8 +874,16 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
     const long long nb = (long long)nqb * p.heads * B;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "flash_attn: grid too large");
     probe_mark(0, stream);
-    hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF>), dim3((unsigned)nb), dim3(256), 0, stream, p, Kp, Vtp, npad, nqb,
-                       (int)nb);
+    // measured (tools/bench_attn.py lsv): hd16 2V 2.18 / 2.02 / 1.83 ms for forms 0 / 1 / 2, hd32 1V 0.53 / 0.51 / 0.47,
+    // hd32 2V 0.258 / 0.223 / 0.234
+    const int lsv = P::SUMROW ? 0 : (g_attn_lsv < 0 ? ((HD == 32 && NV == 2) ? 1 : 2) : (g_attn_lsv & 3));
+    const dim3 grid((unsigned)nb);
+    if (lsv == 2)
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 2>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
+    else if (lsv == 1)
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 1>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
+    else
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, 0>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     probe_mark(1, stream);
     // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
     hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, QG, 2>), dim3(nqb, p.heads, B), dim3(256), 0, stream, p);
@@ -924,9 +970,11 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
             ((uintptr_t)workspace & 255) == 0) {
             // the pack pre-pass also produces max|k|^2
             // (QG, PF) per shape measured on MI355X (tools/bench_attn.py): hd16 1V 4.84 -> 4.72 ms with 4 query groups,
-            // hd16 2V 2.29 -> 2.24 and hd32 1V 0.54 -> 0.53 with one block of prefetch, hd32 2V 0.31 -> 0.26 with (2, 1)
+            // hd16 2V 2.29 -> 2.24 and hd32 1V 0.54 -> 0.53 with one block of prefetch (with the selector-MFMA denominators
+            // hd16 2V runs 1.88 at (2, 1) and 1.83 at (4, 2)), hd32 2V 0.31 -> 0.26 with (2, 1)
             if (hd == 16) return nv == 1 ? launch_attn_packed<16, 1, 4, 2>(p, B, workspace, s)
-                                         : launch_attn_packed<16, 2, 2, 1>(p, B, workspace, s);
+                                         : ((g_attn_lsv >= 0 && (g_attn_lsv & 4)) ? launch_attn_packed<16, 2, 2, 1>(p, B, workspace, s)
+                                                            : launch_attn_packed<16, 2, 4, 2>(p, B, workspace, s));
             return nv == 1 ? launch_attn_packed<32, 1, 2, 1>(p, B, workspace, s)
                            : launch_attn_packed<32, 2, 2, 1>(p, B, workspace, s);
         }
