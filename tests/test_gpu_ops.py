@@ -804,3 +804,40 @@ def test_affine_cast(ops):
         out = torch.full((b * n, c + 8), 4.0, device="cuda", dtype=dt)
         ops.affine_cast(x.cuda()[:, :c], b, n, c, a.cuda(), s.cuda(), out[:, :c])
         assert err(out[:, :c].reshape(b, n, c), ref) < tol and float(out[:, c:].float().min()) == 4.0
+
+
+@pytest.mark.parametrize("shape", [(4096 + 77, 192, 1024), (8192, 576, 1728), (4500, 384, 2048)])
+@pytest.mark.parametrize("epi", ["plain", "bias_scale", "gelu"])
+def test_conv_gemm_wide_tiles(ops, shape, epi):
+    """Large-K bf16 1x1 GEMMs with N % 192 == 0 take the 256 x 192 ring kernel (csrc/gemm_wide.hip): ragged M, every
+    epilogue it accepts, against an fp64 reference and against the 128 x 128 kernel (same sums in another order)."""
+    from underwater_image_restoration_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda() if epi != "plain" else None
+    cs = (torch.rand(N, generator=g) + 0.5).cuda() if epi == "bias_scale" else None
+    act = ops.ACT_GELU if epi == "gelu" else ops.ACT_NONE
+    outs = []
+    for variant in (2, 0):   # 2: keep the 128 x 128 kernel
+        lib.uwir_conv_variant(variant)
+        try:
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ops.conv_gemm(A, W, out, B=1, H=1, W=M, C_=K, N=N, bias=bias, col_scale=cs, act=act)
+            torch.cuda.synchronize()
+        finally:
+            lib.uwir_conv_variant(0)
+        outs.append(out.float())
+    ref = A.double() @ W.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if cs is not None:
+        ref = ref * cs.double()
+    for o in outs:
+        assert bool(torch.isfinite(o).all())
+        assert rel(o, ref.float()) < 4e-3          # bf16 output rounding
+    assert float((outs[0] - outs[1]).abs().max()) <= 2 ** -6 * float(ref.abs().max())   # at most one bf16 ulp apart

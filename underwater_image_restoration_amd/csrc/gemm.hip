@@ -884,9 +884,13 @@ static bool halo_eligible(const uwir_gemm_args& g) {
            g.OH == (g.H << g.ups) && g.OW == (g.W << g.ups) && g.lda % 8 == 0;
 }
 
+static int g_gemm_wide = 1;   // tools/: uwir_conv_variant(2) keeps the large-K GEMMs on the 128 x 128 kernel
 static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
                               // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
-extern "C" void uwir_conv_variant(int th16) { g_halo_th16 = th16; }
+extern "C" void uwir_conv_variant(int v) {
+    g_halo_th16 = v & 1;
+    g_gemm_wide = (v & 2) ? 0 : 1;
+}
 
 template <typename TA>
 static int launch_halo(const GemmP& p0, hipStream_t stream) {
@@ -928,9 +932,15 @@ static int splitk_factor(int M, int N, int K, const void* ws, size_t ws_bytes) {
     return s;
 }
 
+int uwir_gemm_wide_try(const uwir_gemm_args& g, int M, int K, hipStream_t stream);   // gemm_wide.hip
+
 template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
+    if (g_gemm_wide && glds_eligible(p.a, p.K)) {
+        const int took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
+        if (took != 0) return took < 0 ? took : UWIR_OK;
+    }
     int bn = p.a.N <= 64 ? 64 : 128;
     // few-block launches (deep, narrow levels: M = 8192 rows): halve the N tile to double the blocks on the 256 CUs
     if (bn == 128 && (long long)ceil_div(p.M, 128) * ceil_div(p.a.N, 128) < 512 && !glds_eligible(p.a, p.K)) bn = 64;
