@@ -841,3 +841,33 @@ def test_conv_gemm_wide_tiles(ops, shape, epi):
         assert bool(torch.isfinite(o).all())
         assert rel(o, ref.float()) < 4e-3          # bf16 output rounding
     assert float((outs[0] - outs[1]).abs().max()) <= 2 ** -6 * float(ref.abs().max())   # at most one bf16 ulp apart
+
+
+def test_operand_on_another_device_is_an_error(ops):
+    """the library launches in the CURRENT HIP device context, so an operand that lives elsewhere must be
+    refused, not enqueued on the wrong GPU's stream.  (The model-level forwards switch to their input's device
+    themselves: second test, needs two GPUs.)"""
+    cur = torch.cuda.current_device()
+    with pytest.raises(ValueError, match="current HIP device"):
+        ops._stream(torch.device("cuda", cur + 1))
+    with pytest.raises(ValueError, match="current HIP device"):
+        ops._stream(torch.zeros(1))
+    assert ops._stream(torch.zeros(1, device="cuda")) == torch.cuda.current_stream().cuda_stream
+
+
+def test_model_on_non_current_device(ops):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
+    mk = dict(base_channels=16, num_levels=2, blocks_per_level=1, cond_dim=12, num_masks=0, num_degradation_types=3)
+    sd = synth_state_dict(student_param_shapes(**mk), seed=3)
+    x, z, _ = synth_student_inputs(1, 32, 32, 12, 0, seed=4)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        model = NAFNetWFIGate(**mk, precision="fp32")
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        assert torch.cuda.current_device() == 0
+        outs.append(model(x.to(dev), z.to(dev), None)[0].cpu())   # cuda:1 is NOT the current device here
+    assert torch.equal(outs[0], outs[1])

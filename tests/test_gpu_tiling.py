@@ -64,3 +64,29 @@ def test_inplace_windows_equal_the_gather_and_stitch_path(precision):
         model.supports_windows = True
     assert a.shape == x.shape and bool(torch.isfinite(a).all())
     assert torch.equal(a, b)
+
+
+def test_any_size_restorer_pads_and_crops():
+    """Frames whose size is not a multiple of 8: reflect-pad, restore, crop.  Aligned frames are the
+    wrapped call itself; a padded frame equals the aligned pipeline run on the explicitly padded input.  (Against the
+    reference's native odd-size path: parity unpinned, see AnySizeRestorer.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.tiling import AnySizeRestorer, TiledRestorer
+    mk = dict(base_channels=16, num_levels=3, blocks_per_level=1, cond_dim=20, num_masks=10, num_degradation_types=5)
+    model = NAFNetWFIGate(**mk, precision="fp32")
+    model.load_state_dict(synth_state_dict(student_param_shapes(**mk), seed=12))
+    model = model.cuda().eval()
+    anyr = AnySizeRestorer(model, tile=32, halo=8, max_batch=8)
+    x, z, m = synth_student_inputs(2, 45, 77, 20, 10, mask_hw=(7, 7), seed=5)
+    out = anyr(x.cuda(), z.cuda(), m.cuda())
+    assert out.shape == x.shape and bool(torch.isfinite(out).all())
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    xp = torch.nn.functional.pad(x, (0, 3, 0, 3), mode="reflect")
+    ref = TiledRestorer(model, tile=32, halo=8, max_batch=8)(xp.cuda(), z.cuda(), m.cuda())[:, :, :45, :77]
+    assert torch.equal(out, ref)
+    xa, za, ma = synth_student_inputs(1, 48, 80, 20, 10, mask_hw=(7, 7), seed=6)
+    assert torch.equal(anyr(xa.cuda(), za.cuda(), ma.cuda()), TiledRestorer(model, tile=32, halo=8, max_batch=8)(xa.cuda(), za.cuda(), ma.cuda()))
+    with pytest.raises(ValueError):
+        anyr(torch.rand(1, 3, 2, 50).cuda(), z[:1].cuda(), m[:1].cuda())

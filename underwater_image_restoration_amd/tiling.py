@@ -143,3 +143,32 @@ class TiledRestorer:
                 x.shape[0], tiles, x.device), out)
             return out
         return self.stitch(self.run_windows(x, cond, fm, tiles), tiles, H, W)   # generic callables: gather / stitch copies
+
+
+class AnySizeRestorer:
+    """``restorer(x, cond, masks=None) -> restored`` for frames whose H or W is NOT a multiple of 8 (540 x 960, 1080 x
+    1918, ...): reflect-pad bottom / right to the next multiple of 8, restore (through ``TiledRestorer`` when the padded
+    frame is at least one tile), crop.  Aligned sizes pass straight through, bit-identical to the wrapped call.
+
+    Parity unpinned against the reference for the padded sizes: the reference runs such frames at their native size
+    (odd sub-band sizes inside its DWT) and resizes the result bilinearly when it comes out a pixel short
+    (S/model.py:150-151); this wrapper keeps every pixel on the exact aligned path instead and only the <= 7 mirrored
+    rows / columns of context differ.  Masks are frame-level maps that the model resizes to the (padded) frame itself."""
+
+    def __init__(self, model, tile: int = 256, halo: int = 32, max_batch: int = 32) -> None:
+        self.tiled = TiledRestorer(model, tile, halo, max_batch)
+
+    @torch.no_grad()
+    @ops.on_operand_device
+    def __call__(self, x: torch.Tensor, cond: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x.dim() != 4:
+            raise ValueError("Input must be (B, C, H, W).")
+        H, W = x.shape[-2:]
+        ph, pw = (-H) % 8, (-W) % 8
+        if ph == 0 and pw == 0:
+            return self.tiled(x, cond, masks)
+        if ph >= H or pw >= W:
+            raise ValueError("image too small for reflect padding")
+        xp = torch.nn.functional.pad(x.float(), (0, pw, 0, ph), mode="reflect")
+        return self.tiled(xp, cond, masks)[:, :, :H, :W].contiguous()
+
