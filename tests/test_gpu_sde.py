@@ -82,3 +82,36 @@ def test_single_steps_reference_signatures(sde_mod):
         assert max_abs(x0.cpu().numpy(), ((x - mu - tb.sigma_bars[t] * nz) * A + mu).numpy()) < 1e-4
     with pytest.raises(RuntimeError):
         sde.reverse_posterior_step(x, nz, 5)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conditioning_schedule_is_bit_identical(sde_mod, precision):
+    """The sampler asks a ConditionalUNet of this package for the (time, context)-only part of all its steps in one
+    batched pass (unet.conditioning_schedule).  Same rows, same kernels: the loop's result must not change by a bit, and
+    calls that do not match the schedule (other time, other context tensor, tensor time) must still work."""
+    from underwater_image_restoration_amd.synth import synth_state_dict, unet_param_shapes
+    from underwater_image_restoration_amd.unet import ConditionalUNet
+    unet = ConditionalUNet(3, 3, 32, [1, 2], 64, True, True, precision=precision)
+    unet.load_state_dict(synth_state_dict(unet_param_shapes(3, 3, 32, [1, 2], 64, True, True), seed=5))
+    unet = unet.cuda().eval()
+    gen = torch.Generator().manual_seed(3)
+    B = 3
+    mu = torch.rand(B, 3, 32, 32, generator=gen).cuda()
+    tc, ic = torch.randn(B, 64, generator=gen).cuda(), torch.randn(B, 64, generator=gen).cuda()
+    sde = sde_mod.IRSDE(max_sigma=50, T=100, schedule="cosine", eps=0.005, device="cuda")
+    sde.set_mu(mu)
+    xt = mu + torch.randn(mu.shape, generator=gen).cuda() * 0.3
+    tape = torch.randn(5, *mu.shape, generator=gen).cuda()
+    sde.set_model(unet)
+    a = sde.reverse_posterior(xt, T=5, noise_tape=tape, text_context=tc, image_context=ic)
+    sde.set_model(lambda x, m, t, **kw: unet(x, m, t, **kw))       # a plain callable: no schedule, step by step
+    b = sde.reverse_posterior(xt, T=5, noise_tape=tape, text_context=tc, image_context=ic)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    with unet.conditioning_schedule([1.0, 2.0], B, text_context=tc, image_context=ic):
+        in_sched = unet(xt, mu, 2.0, text_context=tc, image_context=ic).clone()
+        other_t = unet(xt, mu, 3.0, text_context=tc, image_context=ic).clone()          # not in the schedule
+        other_c = unet(xt, mu, 2.0, text_context=tc.clone(), image_context=ic).clone()  # another tensor object
+        tens_t = unet(xt, mu, torch.full((B,), 2.0), text_context=tc, image_context=ic).clone()
+    assert torch.equal(in_sched, unet(xt, mu, 2.0, text_context=tc, image_context=ic))
+    assert torch.equal(other_c, in_sched) and torch.equal(tens_t, in_sched)
+    assert torch.equal(other_t, unet(xt, mu, 3.0, text_context=tc, image_context=ic))

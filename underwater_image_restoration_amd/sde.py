@@ -10,6 +10,7 @@ reproducible trajectories; by default noise comes from ``torch.randn_like`` on t
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Optional
 
@@ -198,15 +199,22 @@ class IRSDE:
     def _loop(self, xt, T, mode, noise_tape, kwargs):
         T = self.sample_T if T < 0 else T
         x = xt.clone().contiguous().float()
-        for i, t in enumerate(reversed(range(1, T + 1))):
-            pred = self.noise_fn(x, t, self.sample_scale, **kwargs)
-            eps = None if noise_tape is None else noise_tape[i]
-            if mode == "posterior":
-                x = self.reverse_posterior_step(x, pred, t, eps=eps, out=x)
-            elif mode == "sde":
-                x = self.reverse_sde_step_from_noise(x, pred, t, eps=eps, out=x)
-            else:
-                x = self.reverse_sde_step_from_noise(x, pred, t, eps=False, score_weight=0.5, out=x)
+        # a ConditionalUNet of this package derives everything that depends on (t, contexts) alone for the whole loop in
+        # one batched pass (unet.conditioning_schedule); any other callable is stepped as the reference does
+        sched = getattr(self.model, "conditioning_schedule", None)
+        ok = sched is not None and x.is_cuda and set(kwargs) <= {"text_context", "image_context"}
+        ctx = (sched([t * self.sample_scale for t in range(1, T + 1)], x.shape[0], device=x.device, **kwargs) if ok
+               else contextlib.nullcontext())
+        with ctx:
+            for i, t in enumerate(reversed(range(1, T + 1))):
+                pred = self.noise_fn(x, t, self.sample_scale, **kwargs)
+                eps = None if noise_tape is None else noise_tape[i]
+                if mode == "posterior":
+                    x = self.reverse_posterior_step(x, pred, t, eps=eps, out=x)
+                elif mode == "sde":
+                    x = self.reverse_sde_step_from_noise(x, pred, t, eps=eps, out=x)
+                else:
+                    x = self.reverse_sde_step_from_noise(x, pred, t, eps=False, score_weight=0.5, out=x)
         return x
 
     def reverse_sde(self, xt, T=-1, save_states=False, save_dir="sde_state", noise_tape=None, **kwargs):

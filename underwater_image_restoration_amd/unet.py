@@ -17,6 +17,7 @@ Everything runs NHWC through the C ABI (include/uwir.h); this file owns buffers,
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional
 
@@ -67,6 +68,7 @@ class ConditionalUNet(nn.Module):
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self.fused_linattn = True            # bf16: Residual(PreNorm(LinearAttention)) as two fused passes (csrc/linattn.hip)
         self._emb_cache: Dict[tuple, torch.Tensor] = {}
+        self._schedule: Optional[dict] = None   # conditioning_schedule()
 
     # ------------------------------------------------------------------ parameters
     def set_precision(self, precision: str) -> "ConditionalUNet":
@@ -78,6 +80,7 @@ class ConditionalUNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._pack, self._bufs, self._emb_cache = None, {}, {}
+        self._schedule = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -284,6 +287,68 @@ class ConditionalUNet(nn.Module):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @ops.on_operand_device
+    def _conditioning_rows(self, emb: torch.Tensor, R: int, B: int, text_context, image_context, dev, tag: str):
+        """emb [R, nf] (R = B, or T * B for a schedule) -> (ss_all [R, S], u_all [B, U] or None, st [R, td])."""
+        pk, f32, td = self._pack, torch.float32, 4 * self.nf
+        tcat = self._buf(tag + "tcat", R, 2 * td, f32, dev)
+        ops.linear(emb, pk["t1_w"], pk["t1_b"], tcat[:, :td], ops.ACT_GELU)
+        st = self._buf(tag + "st", R, td, f32, dev)
+        if self._has_prompt and text_context is not None:
+            p1, p2 = self._buf("p1", B, td, f32, dev), self._buf("p2", B, td, f32, dev)
+            ops.linear(text_context.contiguous().float(), pk["x0_w"], pk["x0_b"], p1, ops.ACT_SILU)
+            ops.linear(p1, pk["x2_w"], pk["x2_b"], p2)
+            if R == B:
+                ops.softmax_rows(p2, pk["prompt"], tcat[:, td:])
+            else:   # the prompt half does not depend on the time: one softmax, copied to every step's rows
+                pr = self._buf("prow", B, td, f32, dev)
+                ops.softmax_rows(p2, pk["prompt"], pr)
+                tcat.view(R // B, B, 2 * td)[:, :, td:] = pr
+            ops.linear(tcat, pk["tp_w"], pk["tp_b"], st, ops.ACT_SILU)
+        else:
+            ops.linear(tcat[:, :td], pk["t3_w"], pk["t3_b"], st, ops.ACT_SILU)
+        ss_all = self._buf(tag + "ss_all", R, pk["ss_w"].shape[0], f32, dev)
+        ops.linear(st, pk["ss_w"], pk["ss_b"], ss_all)
+        u_all = None
+        if "ov_w" in pk and self._has_st and image_context is not None:
+            u_all = self._buf(tag + "u_all", B, pk["ov_w"].shape[0], f32, dev)
+            ops.linear(image_context.contiguous().float(), pk["ov_w"], pk["ov_b"], u_all)
+        return ss_all, u_all, st
+
+    def _conditioning(self, time, B: int, text_context, image_context, dev, use_schedule: bool = True):
+        sch = self._schedule if use_schedule else None
+        if sch is not None and not torch.is_tensor(time):
+            i = sch["index"].get(float(time))
+            if (i is not None and sch["B"] == B and sch["dev"] == dev and sch["text"] is text_context
+                    and sch["image"] is image_context):
+                return sch["ss"][i], sch["u"]
+        emb = self._time_embedding(time, B, dev)
+        ss_all, u_all, _ = self._conditioning_rows(emb, B, B, text_context, image_context, dev, "")
+        return ss_all, u_all
+
+    @contextlib.contextmanager
+    def conditioning_schedule(self, times, B: int, text_context=None, image_context=None, device=None):
+        """Everything the UNet derives from (time, text_context, image_context) alone -- the time MLP, the prompt
+        softmax, every ResBlock's (scale + 1 | shift) vector, the cross-attention constants -- for ALL ``times`` of a
+        sampling loop in one batched pass (6 tiny launches per step otherwise: 0.15 of 5.5 ms at B = 8, 256 x 256).
+        Inside the ``with`` block, forward() calls with one of these scalar times, this batch size and these very
+        context tensors take their rows from it; anything else is computed as usual.  Row results of ``ops.linear`` do
+        not depend on how many rows share a launch, so the outputs are bit-identical."""
+        if self._pack is None:
+            self._pack = self._build_pack()
+        dev = device if device is not None else (text_context.device if text_context is not None else
+                                                 image_context.device if image_context is not None else torch.device("cuda"))
+        times = [float(t) for t in times]
+        with torch.cuda.device(dev):
+            emb = torch.cat([self._time_embedding(t, B, dev) for t in times], 0)
+            ss, u, _ = self._conditioning_rows(emb, len(times) * B, B, text_context, image_context, dev, "sch_")
+        prev = self._schedule
+        self._schedule = dict(index={t: i for i, t in enumerate(times)}, B=B, dev=dev, text=text_context, image=image_context,
+                              ss=ss.view(len(times), B, -1), u=u)
+        try:
+            yield self
+        finally:
+            self._schedule = prev
+
     def forward(self, xt: torch.Tensor, cond: torch.Tensor, time, text_context: Optional[torch.Tensor] = None,
                 image_context: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
         if not xt.is_cuda:
@@ -302,25 +367,10 @@ class ConditionalUNet(nn.Module):
         nf, td, lv, D = self.nf, 4 * self.nf, self._levels(), self.depth
         xt, cond = xt.contiguous().float(), cond.contiguous().float()
 
-        # ---- time / prompt embedding -> SiLU(t) -> all ResBlock (scale+1 | shift) vectors in one linear
-        emb = self._time_embedding(time, B, dev)
-        tcat = self._buf("tcat", B, 2 * td, f32, dev)
-        ops.linear(emb, pk["t1_w"], pk["t1_b"], tcat[:, :td], ops.ACT_GELU)
-        st = self._buf("st", B, td, f32, dev)
-        if self._has_prompt and text_context is not None:
-            p1, p2 = self._buf("p1", B, td, f32, dev), self._buf("p2", B, td, f32, dev)
-            ops.linear(text_context.contiguous().float(), pk["x0_w"], pk["x0_b"], p1, ops.ACT_SILU)
-            ops.linear(p1, pk["x2_w"], pk["x2_b"], p2)
-            ops.softmax_rows(p2, pk["prompt"], tcat[:, td:])
-            ops.linear(tcat, pk["tp_w"], pk["tp_b"], st, ops.ACT_SILU)
-        else:
-            ops.linear(tcat[:, :td], pk["t3_w"], pk["t3_b"], st, ops.ACT_SILU)
-        ss_all = self._buf("ss_all", B, pk["ss_w"].shape[0], f32, dev)
-        ops.linear(st, pk["ss_w"], pk["ss_b"], ss_all)
-        u_all = None
-        if "ov_w" in pk and self._has_st and image_context is not None:
-            u_all = self._buf("u_all", B, pk["ov_w"].shape[0], f32, dev)
-            ops.linear(image_context.contiguous().float(), pk["ov_w"], pk["ov_b"], u_all)
+        # ---- time / prompt embedding -> SiLU(t) -> all ResBlock (scale+1 | shift) vectors in one linear (or this
+        # step's rows of a schedule computed once for the whole sampling loop: conditioning_schedule)
+        ss_all, u_all = self._conditioning(time, B, text_context, image_context, dev, use_schedule=taps is None)
+        st = self._bufs.get(("st", B, td, f32)) if taps is not None else None
 
         # ---- buffers: concat buffers per level ([x | skip]); producers write into their column slices
         Hs = [Hp >> i for i in range(D)]
