@@ -40,9 +40,15 @@ template <int G> struct GIdx { static constexpr int value = G; };
 template <typename T, int HD, int NV, int QG, int MODE>
 __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
     constexpr bool BF = sizeof(T) == 2;
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // marks: one int per 128 queries of a (b, head); this block covers QG of them
+    const int nq128 = (p.n + 127) / 128;
+    int* const marks = p.flags ? p.flags + (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * nq128 + blockIdx.x * QG : nullptr;
     if constexpr (MODE == 2) {
-        if (p.flags[blk] == 0) return;  // block-uniform, ahead of every barrier
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < QG; ++i)
+            if (blockIdx.x * QG + i < nq128) any |= marks[i];
+        if (any == 0) return;  // block-uniform, ahead of every barrier
     }
     constexpr int KT = AT_KT;
     constexpr int KSTR = HD + (BF ? 8 : 1);   // sK row stride (elements)
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(AttnP p) {
             }
             if constexpr (MODE == 1) {
                 if (__syncthreads_or(!ok)) {  // block-uniform: leave the whole block to the online-max launch
-                    if (tid == 0) p.flags[blk] = 1;
+                    if (tid < QG && blockIdx.x * QG + tid < nq128) marks[tid] = 1;
                     return;
                 }
                 fast = true;
@@ -656,8 +662,12 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
         q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         ok = ok && (sqrtf(q2 * km2) * 1.002f + 1e-3f <= 90.f);
     }
-    if (__syncthreads_or(!ok)) {  // block-uniform: leave the whole block to the online-max launch
-        if (tid == 0) p.flags[vid] = 1;
+    // wave-uniform (the kernel has no barrier): a wave whose 32 * QG queries do not all pass marks their 128-query
+    // group(s) for the online-max launch and leaves; the other waves of the block carry on
+    if (__any(!ok)) {
+        const int q0 = qb * (128 * QG) + wave * (32 * QG);   // first query of this wave
+        if (lane < (QG + 3) / 4 && q0 + 128 * lane < n)
+            p.flags[(size_t)bh * ((n + 127) / 128) + q0 / 128 + lane] = 1;
         return;
     }
 
@@ -886,7 +896,7 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
         hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, 0>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     probe_mark(1, stream);
     // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
-    hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, QG, 2>), dim3(nqb, p.heads, B), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, 2, 2>), dim3(ceil_div(n, 256), p.heads, B), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("flash_attn(stream)");
     return UWIR_OK;
 }
