@@ -35,7 +35,8 @@ enum uwir_act { UWIR_ACT_NONE = 0, UWIR_ACT_RELU = 1, UWIR_ACT_GELU = 2, UWIR_AC
 int uwir_version(void);
 /* Measurement switch with no counterpart in the reference, for A/B timing in one process (tools/): bit 0 selects the
  * 3x3 halo-conv tile shape (0 = 8-row tiles, the default; 1 = 16-row tiles, identical results), bit 1 keeps the
- * large-K 1x1 GEMMs on the 128 x 128 kernel instead of the 256 x 192 one (same sums in another order). */
+ * large-K 1x1 GEMMs on the 128 x 128 kernel instead of the 256 x 192 one (same sums in another order), bit 2 keeps
+ * the radix-2 FFT line kernel instead of the radix-4 one (same transform, another summation order). */
 void uwir_conv_variant(int variant);
 /* Test / measurement switch, no counterpart in the reference: tiles walked by one block of the pipelined depthwise
  * kernel (0 = chosen from the grid size, the default).  Results are identical for every value. */

@@ -154,6 +154,170 @@ __global__ void __launch_bounds__(256) fft_lines_kernel(FftP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Power-of-two lines, second form.  The radix-2 kernel above moves every point through LDS seven times (L = 128) as
+// 4-byte accesses with a barrier per stage, and is bound by that (LDS 64-128 B/clk for b32 traffic), not by HBM.  Here:
+// in-place decimation-in-frequency with radix-4 stages (one radix-2 stage when log2 L is odd: 4 stages for 128, 3 for
+// 64), every LDS access a 16-byte channel quad (lane = (butterfly, quad): 16 consecutive lanes cover one 256-byte bank
+// row), natural-order load, digit-reversed read at the store.  A block takes as many lines as fill 256 threads with
+// radix-4 butterflies (2 at L = 128, 4 at 64, 8 at 32).  The 1/sqrt(L) scaling, polar conversions and the addend are
+// fused into the load / store as before.
+// ------------------------------------------------------------------------------------------
+struct Cx4 { float4 r, i; };
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ Cx4 cadd(Cx4 a, Cx4 b) { return {f4add(a.r, b.r), f4add(a.i, b.i)}; }
+__device__ __forceinline__ Cx4 csub(Cx4 a, Cx4 b) { return {f4sub(a.r, b.r), f4sub(a.i, b.i)}; }
+__device__ __forceinline__ Cx4 cmulw(Cx4 a, float wr, float wi) {   // a * (wr + i wi)
+    Cx4 o;
+    o.r = make_float4(a.r.x * wr - a.i.x * wi, a.r.y * wr - a.i.y * wi, a.r.z * wr - a.i.z * wi, a.r.w * wr - a.i.w * wi);
+    o.i = make_float4(a.r.x * wi + a.i.x * wr, a.r.y * wi + a.i.y * wr, a.r.z * wi + a.i.z * wr, a.r.w * wi + a.i.w * wr);
+    return o;
+}
+
+#define FFT4_CS 16   // channels per block slab: 64 bytes per pixel, 4 quads
+
+template <int MODE>
+__global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int nlb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CS = FFT4_CS, Q4 = CS / 4;
+    constexpr bool ROWS = (MODE == FFT_FWD_ROWS || MODE == FFT_INV_ROWS);
+    constexpr bool INV = (MODE == FFT_INV_COLS || MODE == FFT_INV_ROWS);
+    const int L = p.L, tid = threadIdx.x;
+    float* re = smem;                 // [nlb][L][CS]
+    float* im = re + nlb * L * CS;
+    float* twr = im + nlb * L * CS;   // [L]
+    float* twi = twr + L;
+    const int c0 = blockIdx.y * CS;
+    const int ncs = min(CS, p.C - c0);
+    const int line0 = blockIdx.x * nlb;
+
+    for (int k = tid; k < L; k += 256) {
+        float s, c;
+        sincospif(2.0f * (float)k / (float)L, &s, &c);
+        twr[k] = c;
+        twi[k] = INV ? s : -s;
+    }
+    auto pixel = [&](int line, int j) -> size_t {
+        const int b = ROWS ? line / p.H : line / p.W, fixed = ROWS ? line % p.H : line % p.W;
+        return ROWS ? ((size_t)b * p.H + fixed) * p.W + j : ((size_t)b * p.H + j) * p.W + fixed;
+    };
+    // ---- load (natural order).  nlb * L == 256 (host), so a thread has exactly 4 (pixel, quad) items: all of their
+    // global loads are issued before the first LDS store (a rolled load -> store loop exposes one HBM round trip per item)
+    float4 lr[4], li[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + 256 * it;
+        const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
+        lr[it] = make_float4(0, 0, 0, 0);
+        li[it] = make_float4(0, 0, 0, 0);
+        if (4 * q < ncs && line < nlines) {
+            const size_t px = pixel(line, j);
+            lr[it] = load4(p.in0 + px * p.ld_in + c0 + 4 * q);
+            if (MODE != FFT_FWD_ROWS) li[it] = load4(p.in1 + px * p.ld_in + c0 + 4 * q);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + 256 * it;
+        const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L);
+        float4 vr = lr[it], vi = li[it];
+        if (MODE == FFT_INV_COLS) {   // (amp, phase) -> complex
+            const float4 a = lr[it], ph = li[it];
+            float s, c;
+            sincosf(ph.x, &s, &c); vr.x = a.x * c; vi.x = a.x * s;
+            sincosf(ph.y, &s, &c); vr.y = a.y * c; vi.y = a.y * s;
+            sincosf(ph.z, &s, &c); vr.z = a.z * c; vi.z = a.z * s;
+            sincosf(ph.w, &s, &c); vr.w = a.w * c; vi.w = a.w * s;
+        }
+        *reinterpret_cast<float4*>(&re[(ll * L + j) * CS + 4 * q]) = vr;
+        *reinterpret_cast<float4*>(&im[(ll * L + j) * CS + 4 * q]) = vi;
+    }
+    __syncthreads();
+
+    // ---- in-place DIF stages: sub-transform size ns, radix r; butterfly k of group g touches g*ns + k + i*(ns/r)
+    auto ldc = [&](int idx) { Cx4 v; v.r = *reinterpret_cast<const float4*>(&re[idx]); v.i = *reinterpret_cast<const float4*>(&im[idx]); return v; };
+    auto stc = [&](int idx, Cx4 v) { *reinterpret_cast<float4*>(&re[idx]) = v.r; *reinterpret_cast<float4*>(&im[idx]) = v.i; };
+    int ns = L;
+    while (ns >= 4) {
+        const int qs = ns >> 2, tstep = L / ns;
+        for (int i = tid; i < nlb * (L >> 2) * Q4; i += 256) {
+            const int q = i % Q4, t = (i / Q4) % (L >> 2), ll = i / (Q4 * (L >> 2));
+            const int g = t / qs, k = t - g * qs;
+            const int base = ((ll * L + g * ns + k) * CS) + 4 * q, st = qs * CS;
+            const Cx4 a0 = ldc(base), a1 = ldc(base + st), a2 = ldc(base + 2 * st), a3 = ldc(base + 3 * st);
+            const Cx4 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+            // forward: (-i) d = (d.i, -d.r); inverse: (+i) d = (-d.i, d.r)
+            const Cx4 t3 = INV ? Cx4{f4neg(d.i), d.r} : Cx4{d.i, f4neg(d.r)};
+            const Cx4 y0 = cadd(t0, t2), y2 = csub(t0, t2), y1 = cadd(t1, t3), y3 = csub(t1, t3);
+            const int w1 = k * tstep, w2 = 2 * w1, w3 = 3 * w1;   // < L: k < ns/4
+            stc(base, y0);
+            stc(base + st, cmulw(y1, twr[w1], twi[w1]));
+            stc(base + 2 * st, cmulw(y2, twr[w2], twi[w2]));
+            stc(base + 3 * st, cmulw(y3, twr[w3], twi[w3]));
+        }
+        __syncthreads();
+        ns = qs;
+    }
+    if (ns == 2) {   // last stage of an odd log2 L: k = 0 only, twiddle 1
+        for (int i = tid; i < nlb * (L >> 1) * Q4; i += 256) {
+            const int q = i % Q4, t = (i / Q4) % (L >> 1), ll = i / (Q4 * (L >> 1));
+            const int base = ((ll * L + 2 * t) * CS) + 4 * q;
+            const Cx4 a0 = ldc(base), a1 = ldc(base + CS);
+            stc(base, cadd(a0, a1));
+            stc(base + CS, csub(a0, a1));
+        }
+        __syncthreads();
+    }
+
+    // ---- store: frequency (or sample) j sits at the digit-reversed position
+    const float nrm = p.norm;
+    float4 ad[4];
+    if (MODE == FFT_INV_ROWS) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it;
+            const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
+            ad[it] = make_float4(0, 0, 0, 0);
+            if (4 * q < ncs && line < nlines) ad[it] = load4(p.addend + pixel(line, j) * p.ld_add + c0 + 4 * q);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + 256 * it;
+        const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
+        if (4 * q >= ncs || line >= nlines) continue;
+        int pos = 0, kk = j, sz = L;
+        while (sz >= 4) { pos += (kk & 3) * (sz >> 2); kk >>= 2; sz >>= 2; }
+        if (sz == 2) pos += kk & 1;
+        float4 vr = *reinterpret_cast<const float4*>(&re[(ll * L + pos) * CS + 4 * q]);
+        float4 vi = *reinterpret_cast<const float4*>(&im[(ll * L + pos) * CS + 4 * q]);
+        vr.x *= nrm; vr.y *= nrm; vr.z *= nrm; vr.w *= nrm;
+        vi.x *= nrm; vi.y *= nrm; vi.z *= nrm; vi.w *= nrm;
+        const size_t px = pixel(line, j);
+        if (MODE == FFT_FWD_COLS) {
+            // bins with ky in {0,H/2} and kx in {0,W/2} of a real signal are exactly real: pin Im = +0
+            const int fixed = line % p.W;
+            const bool fx_self = fixed == 0 || (p.W % 2 == 0 && fixed == p.W / 2);
+            if (fx_self && (j == 0 || (p.H % 2 == 0 && j == p.H / 2))) vi = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a, ph;
+            a.x = hypotf(vr.x, vi.x); ph.x = atan2f(vi.x, vr.x);
+            a.y = hypotf(vr.y, vi.y); ph.y = atan2f(vi.y, vr.y);
+            a.z = hypotf(vr.z, vi.z); ph.z = atan2f(vi.z, vr.z);
+            a.w = hypotf(vr.w, vi.w); ph.w = atan2f(vi.w, vr.w);
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, a);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, ph);
+        } else if (MODE == FFT_INV_ROWS) {
+            vr.x += ad[it].x; vr.y += ad[it].y; vr.z += ad[it].z; vr.w += ad[it].w;
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+        } else {
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, vi);
+        }
+    }
+}
+
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -168,6 +332,9 @@ static int pick_cs(int L, bool pow2) {
     return cs;
 }
 
+static int g_fft_radix4 = 1;   // tools/: uwir_conv_variant bit 2 keeps the radix-2 kernel
+void uwir_fft_set_radix4(int on) { g_fft_radix4 = on; }
+
 template <int MODE>
 static int launch_fft(FftP p, int B, hipStream_t stream) {
     const bool rows = (MODE == FFT_FWD_ROWS || MODE == FFT_INV_ROWS);
@@ -176,6 +343,18 @@ static int launch_fft(FftP p, int B, hipStream_t stream) {
     const bool pow2 = p.logL >= 0;
     p.CS = pick_cs(p.L, pow2);
     p.norm = 1.0f / sqrtf((float)p.L);
+    const int nlines_all = rows ? B * p.H : B * p.W;
+    if (pow2 && p.L >= 4 && p.L <= 256 && g_fft_radix4) {
+        const int nlb = 256 / p.L;   // nlb * L == 256: one radix-4 butterfly and 4 load / store items per thread
+        const size_t lds4 = ((size_t)2 * nlb * p.L * FFT4_CS + 2 * (size_t)p.L) * sizeof(float);
+        if (lds4 <= 64 * 1024) {
+            p.CS = FFT4_CS;
+            dim3 grid4(ceil_div(nlines_all, nlb), ceil_div(p.C, FFT4_CS));
+            hipLaunchKernelGGL((fft_lines4_kernel<MODE>), grid4, dim3(256), lds4, stream, p, nlines_all, nlb);
+            UWIR_LAUNCH_CHECK("fft_lines4");
+            return UWIR_OK;
+        }
+    }
     size_t lds = ((size_t)(pow2 ? 2 : 4) * p.L * p.CS + 2 * (size_t)p.L) * sizeof(float);
     if (lds > 64 * 1024) return uwir_set_error(UWIR_EUNSUPPORTED, "fft: line length %d too large", p.L);
     int nlines = rows ? B * p.H : B * p.W;

@@ -887,9 +887,11 @@ static bool halo_eligible(const uwir_gemm_args& g) {
 static int g_gemm_wide = 1;   // tools/: uwir_conv_variant(2) keeps the large-K GEMMs on the 128 x 128 kernel
 static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
                               // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
+void uwir_fft_set_radix4(int on);   // fft.hip
 extern "C" void uwir_conv_variant(int v) {
     g_halo_th16 = v & 1;
     g_gemm_wide = (v & 2) ? 0 : 1;
+    uwir_fft_set_radix4((v & 4) ? 0 : 1);
 }
 
 template <typename TA>
