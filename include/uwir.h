@@ -191,8 +191,8 @@ int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* 
 /* ---- S/dwt_fft.py:61-72 fft2 / ifft2 (norm="ortho", full complex spectrum) ------------------
  * fwd: x [B,H,W,C] fp32 -> amp = |F|, phase = atan2(Im,Re) (both [B,H,W,C], stride ld_out).
  * inv: out = addend + Re(ifft2(amp*exp(i*phase)))  (S/sffb.py:52-54: spatial + freq).
- * workspace: >= uwir_fft_workspace_bytes(B,H,W,C).  H, W <= 1024; powers of two use an LDS
- * radix-2 FFT, other lengths a direct DFT. C % 4 == 0. */
+ * workspace: >= uwir_fft_workspace_bytes(B,H,W,C).  H, W <= 1024; line lengths that are powers of two (<= 256) use an
+ * in-LDS radix-4 FFT, other lengths of the form 2^a 3^b 5^c a mixed-radix one, anything else a direct DFT.  C % 4 == 0. */
 size_t uwir_fft_workspace_bytes(int B, int H, int W, int C);
 int uwir_fft2_amp_phase(const float* x, int ldx, int B, int H, int W, int C, float* amp, float* phase, int ld_out,
                         void* workspace, size_t workspace_bytes, uwir_stream_t stream);

@@ -11,7 +11,10 @@ from underwater_image_restoration_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for B, H, W, C in ((16, 128, 128, 64), (16, 64, 64, 128), (16, 32, 32, 256)):
+shapes = ((16, 128, 128, 64), (16, 64, 64, 128), (16, 32, 32, 256))
+if len(sys.argv) > 2 and sys.argv[2] == "mixed":   # sub-band maps of a 240 x 320 image: 2^a 3^b 5^c lines (old form: direct DFT)
+    shapes = ((16, 120, 160, 64), (16, 60, 80, 128), (16, 30, 40, 256), (1, 270, 480, 64))
+for B, H, W, C in shapes:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B * H * W, C, generator=g).cuda()
     add = torch.randn(B * H * W, C, generator=g).cuda()
@@ -36,7 +39,7 @@ for B, H, W, C in ((16, 128, 128, 64), (16, 64, 64, 128), (16, 32, 32, 256)):
             ts.append(e0.elapsed_time(e1) / reps)
         res[variant] = (amp.clone(), out.clone())
         by_f, by_i = x.numel() * 4 * 3, x.numel() * 4 * 4
-        print(f"{'radix-2' if variant else 'radix-4'} B{B} {H}x{W} C{C}: fft2 {ts[0]*1e3:7.1f} us ({by_f/ts[0]/1e6:5.0f} GB/s algorithmic)  "
+        print(f"{'radix-2 / direct DFT' if variant else 'radix-4 / mixed radix'} B{B} {H}x{W} C{C}: fft2 {ts[0]*1e3:7.1f} us ({by_f/ts[0]/1e6:5.0f} GB/s algorithmic)  "
               f"ifft2 {ts[1]*1e3:7.1f} us ({by_i/ts[1]/1e6:5.0f} GB/s)")
     lib.uwir_conv_variant(0)
     # x -> fft -> ifft (+ addend) must give x + addend back

@@ -318,6 +318,158 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Lines whose length is 2^a 3^b 5^c but not a power of two (the sub-band maps of 1080p / 720p / VGA-sized frames: 540,
+// 270, 135, 480, 240, 120, 360, 180, 90 ...): the same in-place decimation-in-frequency scheme with a host-chosen radix
+// schedule out of {4, 2, 3, 5}, generic loops instead of the fixed one-butterfly-per-thread mapping.  Before this kernel
+// such lines took the O(L^2) direct DFT (120 points: 15x the work).  Other lengths still do.
+// ------------------------------------------------------------------------------------------
+#define FFT_MAXST 12
+struct FftSched { int n; int radix[FFT_MAXST]; };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) fft_linesmr_kernel(FftP p, FftSched sc, int nlines, int nlb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool ROWS = (MODE == FFT_FWD_ROWS || MODE == FFT_INV_ROWS);
+    constexpr bool INV = (MODE == FFT_INV_COLS || MODE == FFT_INV_ROWS);
+    const int L = p.L, CS = p.CS, Q4 = CS / 4, tid = threadIdx.x;
+    float* re = smem;                 // [nlb][L][CS]
+    float* im = re + nlb * L * CS;
+    float* twr = im + nlb * L * CS;   // [L]
+    float* twi = twr + L;
+    const int c0 = blockIdx.y * CS;
+    const int ncs = min(CS, p.C - c0);
+    const int line0 = blockIdx.x * nlb;
+
+    for (int k = tid; k < L; k += 256) {
+        float s, c;
+        sincospif(2.0f * (float)k / (float)L, &s, &c);
+        twr[k] = c;
+        twi[k] = INV ? s : -s;
+    }
+    auto pixel = [&](int line, int j) -> size_t {
+        const int b = ROWS ? line / p.H : line / p.W, fixed = ROWS ? line % p.H : line % p.W;
+        return ROWS ? ((size_t)b * p.H + fixed) * p.W + j : ((size_t)b * p.H + j) * p.W + fixed;
+    };
+    for (int i = tid; i < nlb * L * Q4; i += 256) {
+        const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
+        float4 vr = make_float4(0, 0, 0, 0), vi = make_float4(0, 0, 0, 0);
+        if (4 * q < ncs && line < nlines) {
+            const size_t px = pixel(line, j);
+            vr = load4(p.in0 + px * p.ld_in + c0 + 4 * q);
+            if (MODE != FFT_FWD_ROWS) vi = load4(p.in1 + px * p.ld_in + c0 + 4 * q);
+            if (MODE == FFT_INV_COLS) {
+                const float4 a = vr, ph = vi;
+                float s, c;
+                sincosf(ph.x, &s, &c); vr.x = a.x * c; vi.x = a.x * s;
+                sincosf(ph.y, &s, &c); vr.y = a.y * c; vi.y = a.y * s;
+                sincosf(ph.z, &s, &c); vr.z = a.z * c; vi.z = a.z * s;
+                sincosf(ph.w, &s, &c); vr.w = a.w * c; vi.w = a.w * s;
+            }
+        }
+        *reinterpret_cast<float4*>(&re[(ll * L + j) * CS + 4 * q]) = vr;
+        *reinterpret_cast<float4*>(&im[(ll * L + j) * CS + 4 * q]) = vi;
+    }
+    __syncthreads();
+
+    auto ldc = [&](int idx) { Cx4 v; v.r = *reinterpret_cast<const float4*>(&re[idx]); v.i = *reinterpret_cast<const float4*>(&im[idx]); return v; };
+    auto stc = [&](int idx, Cx4 v) { *reinterpret_cast<float4*>(&re[idx]) = v.r; *reinterpret_cast<float4*>(&im[idx]) = v.i; };
+    // multiply by -i (forward) / +i (inverse): the quarter turn of this transform direction
+    auto rot = [&](Cx4 d) { return INV ? Cx4{f4neg(d.i), d.r} : Cx4{d.i, f4neg(d.r)}; };
+    auto scl = [&](Cx4 a, float f) { return Cx4{make_float4(a.r.x * f, a.r.y * f, a.r.z * f, a.r.w * f), make_float4(a.i.x * f, a.i.y * f, a.i.z * f, a.i.w * f)}; };
+    int ns = L;
+    for (int stg = 0; stg < sc.n; ++stg) {
+        const int r = sc.radix[stg], qs = ns / r, tstep = L / ns;
+        for (int i = tid; i < nlb * (L / r) * Q4; i += 256) {
+            const int q = i % Q4, t = (i / Q4) % (L / r), ll = i / (Q4 * (L / r));
+            const int g = t / qs, k = t - g * qs;
+            const int base = ((ll * L + g * ns + k) * CS) + 4 * q, st = qs * CS;
+            const int w1 = k * tstep;   // output i is twiddled by tw[i * w1]: i * k < ns, so the index stays below L
+            if (r == 4) {
+                const Cx4 a0 = ldc(base), a1 = ldc(base + st), a2 = ldc(base + 2 * st), a3 = ldc(base + 3 * st);
+                const Cx4 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = rot(csub(a1, a3));
+                stc(base, cadd(t0, t2));
+                stc(base + st, cmulw(cadd(t1, t3), twr[w1], twi[w1]));
+                stc(base + 2 * st, cmulw(csub(t0, t2), twr[2 * w1], twi[2 * w1]));
+                stc(base + 3 * st, cmulw(csub(t1, t3), twr[3 * w1], twi[3 * w1]));
+            } else if (r == 2) {
+                const Cx4 a0 = ldc(base), a1 = ldc(base + st);
+                stc(base, cadd(a0, a1));
+                stc(base + st, cmulw(csub(a0, a1), twr[w1], twi[w1]));
+            } else if (r == 3) {
+                const Cx4 a0 = ldc(base), a1 = ldc(base + st), a2 = ldc(base + 2 * st);
+                const Cx4 t1 = cadd(a1, a2), t2 = csub(a0, scl(t1, 0.5f)), t3 = rot(scl(csub(a1, a2), 0.86602540378443864676f));
+                stc(base, cadd(a0, t1));
+                stc(base + st, cmulw(cadd(t2, t3), twr[w1], twi[w1]));
+                stc(base + 2 * st, cmulw(csub(t2, t3), twr[2 * w1], twi[2 * w1]));
+            } else {   // 5
+                const Cx4 a0 = ldc(base), a1 = ldc(base + st), a2 = ldc(base + 2 * st), a3 = ldc(base + 3 * st), a4 = ldc(base + 4 * st);
+                const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+                const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+                const Cx4 t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+                const Cx4 m1 = cadd(a0, cadd(scl(t1, c1), scl(t2, c2))), m2 = cadd(a0, cadd(scl(t1, c2), scl(t2, c1)));
+                const Cx4 n1 = rot(cadd(scl(t3, s1), scl(t4, s2))), n2 = rot(csub(scl(t3, s2), scl(t4, s1)));
+                stc(base, cadd(a0, cadd(t1, t2)));
+                stc(base + st, cmulw(cadd(m1, n1), twr[w1], twi[w1]));
+                stc(base + 2 * st, cmulw(cadd(m2, n2), twr[2 * w1], twi[2 * w1]));
+                stc(base + 3 * st, cmulw(csub(m2, n2), twr[3 * w1], twi[3 * w1]));
+                stc(base + 4 * st, cmulw(csub(m1, n1), twr[4 * w1], twi[4 * w1]));
+            }
+        }
+        __syncthreads();
+        ns = qs;
+    }
+
+    const float nrm = p.norm;
+    for (int i = tid; i < nlb * L * Q4; i += 256) {
+        const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
+        if (4 * q >= ncs || line >= nlines) continue;
+        int pos = 0, kk = j, sz = L;
+        for (int stg = 0; stg < sc.n; ++stg) {
+            const int r = sc.radix[stg];
+            pos += (kk % r) * (sz / r);
+            kk /= r;
+            sz /= r;
+        }
+        float4 vr = *reinterpret_cast<const float4*>(&re[(ll * L + pos) * CS + 4 * q]);
+        float4 vi = *reinterpret_cast<const float4*>(&im[(ll * L + pos) * CS + 4 * q]);
+        vr.x *= nrm; vr.y *= nrm; vr.z *= nrm; vr.w *= nrm;
+        vi.x *= nrm; vi.y *= nrm; vi.z *= nrm; vi.w *= nrm;
+        const size_t px = pixel(line, j);
+        if (MODE == FFT_FWD_COLS) {
+            const int fixed = line % p.W;
+            const bool fx_self = fixed == 0 || (p.W % 2 == 0 && fixed == p.W / 2);
+            if (fx_self && (j == 0 || (p.H % 2 == 0 && j == p.H / 2))) vi = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a, ph;
+            a.x = hypotf(vr.x, vi.x); ph.x = atan2f(vi.x, vr.x);
+            a.y = hypotf(vr.y, vi.y); ph.y = atan2f(vi.y, vr.y);
+            a.z = hypotf(vr.z, vi.z); ph.z = atan2f(vi.z, vr.z);
+            a.w = hypotf(vr.w, vi.w); ph.w = atan2f(vi.w, vr.w);
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, a);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, ph);
+        } else if (MODE == FFT_INV_ROWS) {
+            float4 ad = load4(p.addend + px * p.ld_add + c0 + 4 * q);
+            vr.x += ad.x; vr.y += ad.y; vr.z += ad.z; vr.w += ad.w;
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+        } else {
+            store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
+            store4(p.out1 + px * p.ld_out + c0 + 4 * q, vi);
+        }
+    }
+}
+
+// radix schedule for L = 2^a 3^b 5^c (4s first, then a 2, then 3s and 5s); n = 0 if L has another prime factor
+static FftSched fft_schedule(int L) {
+    FftSched s = {};
+    int v = L;
+    while (v % 4 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 4; v /= 4; }
+    while (v % 2 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 2; v /= 2; }
+    while (v % 3 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 3; v /= 3; }
+    while (v % 5 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 5; v /= 5; }
+    if (v != 1) s.n = 0;
+    return s;
+}
+
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -358,6 +510,23 @@ static int launch_fft(FftP p, int B, hipStream_t stream) {
     size_t lds = ((size_t)(pow2 ? 2 : 4) * p.L * p.CS + 2 * (size_t)p.L) * sizeof(float);
     if (lds > 64 * 1024) return uwir_set_error(UWIR_EUNSUPPORTED, "fft: line length %d too large", p.L);
     int nlines = rows ? B * p.H : B * p.W;
+    if (!pow2 && p.L >= 6 && g_fft_radix4) {
+        const FftSched sc = fft_schedule(p.L);
+        int cs = 16;
+        while (cs > 4 && ((size_t)2 * p.L * cs + 2 * (size_t)p.L) * sizeof(float) > 60 * 1024) cs >>= 1;
+        const size_t per_line = (size_t)2 * p.L * cs * sizeof(float);
+        if (sc.n > 0 && per_line + 8 * (size_t)p.L <= 60 * 1024) {
+            // lines per block: fill 256 threads with the widest stage's butterflies, within the LDS budget
+            int nlb = max(1, 256 / max(1, (p.L / 2) * (cs / 4)));
+            while (nlb > 1 && nlb * per_line + 8 * (size_t)p.L > 60 * 1024) --nlb;
+            p.CS = cs;
+            const size_t ldsm = nlb * per_line + 8 * (size_t)p.L;
+            dim3 gridm(ceil_div(nlines_all, nlb), ceil_div(p.C, cs));
+            hipLaunchKernelGGL((fft_linesmr_kernel<MODE>), gridm, dim3(256), ldsm, stream, p, sc, nlines_all, nlb);
+            UWIR_LAUNCH_CHECK("fft_lines(mixed radix)");
+            return UWIR_OK;
+        }
+    }
     dim3 grid(nlines, ceil_div(p.C, p.CS));
     hipLaunchKernelGGL((fft_lines_kernel<MODE>), grid, dim3(256), lds, stream, p);
     UWIR_LAUNCH_CHECK("fft_lines");
