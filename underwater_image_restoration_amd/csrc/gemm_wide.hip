@@ -11,9 +11,11 @@
 // The two wave rows run half a stage apart (see the loop), so one row's MFMAs cover the other's barrier, DMA issue and
 // fragment reads.  bf16 outputs leave through LDS as whole 96-byte row segments.
 //
-// Measured (MI355X, tools/bench_gemm.py wide; random operands): M262144 N576 K1728 0.651 -> 0.570 ms (915 TF/s),
-// M65536 N1152 K3456 0.526 -> 0.522, M16384 N2304 K6912 0.552 -> 0.507 (1029 TF/s).  What was tried on the way, same
-// shapes: 4 waves of 128 x 96 (32x32x16 MFMAs, AGPR accumulators, one wave per SIMD, register-double-buffered
+// Measured (MI355X, tools/exp/abab.py: alternating A/B/A/B after a warm-up -- the first configuration timed in a process
+// reads 10-15 % slow, which made an earlier A-then-B figure for K = 1728 look like a gain): M262144 N576 K1728 0.565 vs
+// 0.565 ms (equal, 925 TF/s), M65536 N1152 K3456 0.516 -> 0.512, M16384 N2304 K6912 0.543 -> 0.488 (1070 TF/s): the
+// wide tile pays where K is long enough to amortise its prologue/epilogue at one block per CU.  What was tried on the
+// way, same shapes: 4 waves of 128 x 96 (32x32x16 MFMAs, AGPR accumulators, one wave per SIMD, register-double-buffered
 // fragments) 0.64 / 0.56 ms -- with the MFMAs or the DMA compiled out in turn it took 0.53 / 0.53 of a 0.30 ms
 // skeleton, i.e. the two did not overlap at all; 8 waves in lock step 0.62 / 0.55; ring depth 3 / 4 / 5: 0.75 / 0.64 /
 // 0.64 (latency is covered from depth 4 on).  Not built: a persistent form that keeps the ring full across output tiles
