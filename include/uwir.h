@@ -123,7 +123,7 @@ typedef struct uwir_gemm_args {
     const float* bias;       /* [N] or NULL */
     const float* batch_bias; /* [B, N] or NULL (per-sample bias, e.g. folded cond_proj of the gate) */
     int act;                 /* uwir_act, applied to (acc + bias) * batch_scale + batch_bias */
-    const float* res;        /* optional fp32 residual [M, ldr] added after act */
+    const void* res;         /* optional residual [M, ldr] of res_dtype (fp32 unless set) added after act */
     int ldr;
     const float* res_scale;  /* optional [B, N]: residual enters as res*res_scale + res_shift */
     const float* res_shift;
@@ -150,6 +150,8 @@ typedef struct uwir_gemm_args {
                                  into slices, one block each, summed in slice order by a second small launch
                                  (bit-reproducible).  Calls sharing a workspace must be ordered on one stream. */
     size_t workspace_bytes;
+    int res_dtype;            /* dtype of res: UWIR_F32 (0, the default) or UWIR_BF16 (the IR-SDE UNet's bf16 activation
+                                 stream); an affine residual (res_scale) and the lean epilogue classes take fp32 rows */
 } uwir_gemm_args;
 size_t uwir_conv_gemm_workspace_bytes(const uwir_gemm_args* args); /* 0 when the launch would not use one */
 int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);
@@ -250,9 +252,10 @@ int uwir_sde_posterior_step(const float* x, const float* mu, const float* noise,
  * y[m,:] = LN(x[m,:] + add[m % add_period,:]) * gamma + beta (+ res[m,:]) over the C channels of row m (biased
  * variance, eps inside the sqrt).  add may be NULL (else [add_period, add_ld]: the ViT's positional + class
  * embedding, transformer.py:527-536); beta may be NULL; res (fp32, row stride ldr) may be NULL, else it is the
- * skip of Residual(PreNorm(..)) added after the norm (module_util.py:27-33).  x fp32 (row stride ldx), y fp32 or
- * bf16 (row stride ldy), y may alias x or res when fp32.  C % 4 == 0. */
-int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
+ * skip of Residual(PreNorm(..)) added after the norm (module_util.py:27-33).  x fp32 or bf16 (x_dtype, row stride
+ * ldx; statistics in fp32 either way), y fp32 or bf16 (row stride ldy), y may alias x or res when all are fp32.
+ * C % 4 == 0. */
+int uwir_ln_rows(const void* x, int x_dtype, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
                  const float* gamma, const float* beta, float eps, const float* res, size_t ldr, void* y, int y_dtype,
                  size_t ldy, uwir_stream_t stream);
 
@@ -263,9 +266,10 @@ int uwir_patchify(const float* img_nchw, int B, int Cin, int H, int W, int P, vo
                   uwir_stream_t stream);
 
 /* ---- `x += control.pop()` with materialised hiddens (L/open_clip/transformer.py:367-368) and other plain
- * residual adds: out[m,:] = a[m,:] + b[m,:], fp32 row matrices, out may alias a or b.  C % 4 == 0. */
-int uwir_add_rows(const float* a, size_t lda, const float* b, size_t ldb, float* out, size_t ldo, int M, int C,
-                  uwir_stream_t stream);
+ * residual adds: out[m,:] = a[m,:] + b[m,:]; a fp32, b and out fp32 or bf16 row matrices (b_dtype / out_dtype: the
+ * IR-SDE UNet's activation stream is bf16 in bf16 mode), out may alias a (as fp32) or b (same dtype).  C % 4 == 0. */
+int uwir_add_rows(const float* a, size_t lda, const void* b, int b_dtype, size_t ldb, void* out, int out_dtype, size_t ldo,
+                  int M, int C, uwir_stream_t stream);
 
 /* ======================= IR-SDE score network (U = L/config/daclip-sde/models/modules/) ======================= */
 
@@ -296,13 +300,14 @@ int uwir_linear_attention(const void* qkv, int dtype, int ld, int B, int n, int 
  *   out[m,:] = LN_{g_out}( W_out . LA( W_qkv . LN_{g_pre}(x)[.] )[m] + b_out ) + x[m,:]
  * Everything after the context reduction is row-local, so the block is two passes over x (+ a tiny combine): pass 1
  * builds ctx[b,h] = softmax_n(k) v^T / n with an online max over the rows, pass 2 does q-softmax, ctx product, to_out,
- * the output LayerNorm and the residual.  x, out fp32 [B*n, ld]; w_qkv bf16 [3*heads*32, dim] (rows q | k | v),
+ * the output LayerNorm and the residual.  x, out [B*n, ld] of io_dtype (fp32, or bf16 = the UNet's bf16 activation
+ * stream; statistics and accumulation stay fp32); w_qkv bf16 [3*heads*32, dim] (rows q | k | v),
  * w_out bf16 [dim, heads*32]; heads must be 4, dim 64 / 128 / 256 (the reference's LinearAttention sizes); out may not
  * alias x.  workspace >= uwir_linattn_block_workspace_bytes(B, n), 16-byte aligned.  Same function as the unfused
  * sequence uwir_ln_rows -> uwir_conv_gemm -> uwir_linear_attention -> uwir_conv_gemm -> uwir_ln_rows to bf16 rounding. */
 size_t uwir_linattn_block_workspace_bytes(int B, int n);
-int uwir_linattn_block(const float* x, int ldx, int B, int n, int dim, int heads, const float* g_pre, const void* w_qkv,
-                       const void* w_out, const float* b_out, const float* g_out, float eps, float* out, int ldo,
+int uwir_linattn_block(const void* x, int io_dtype, int ldx, int B, int n, int dim, int heads, const float* g_pre,
+                       const void* w_qkv, const void* w_out, const float* b_out, const float* g_out, float eps, void* out, int ldo,
                        void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
 /* ---- GEGLU gate, U/attention.py:37-44: h [M, 2F] = [value | gate] -> out [M, F] = value * gelu(gate) (exact GELU);
@@ -314,10 +319,10 @@ int uwir_geglu(const void* h, int dtype, size_t ldh, int M, int F, void* out, si
 int uwir_softmax_rows(const float* x, int ldx, int B, int C, const float* mul, float* y, int ldy, uwir_stream_t stream);
 
 /* ---- final_conv Conv2d(nf, out_nc, 3, 1, 1) + crop x[..., :H, :W], U/DenoisingUNet_arch.py:170-172 ----------------
- * x NHWC fp32 [B,H,W,Cin] (padded size) -> out NCHW fp32 [B,Cout,Ho,Wo] (top-left crop), w repacked [Cout,3,3,Cin],
+ * x NHWC fp32 or bf16 (x_dtype; bf16 needs Cin % 16 == 0) [B,H,W,Cin] (padded size) -> out NCHW fp32 [B,Cout,Ho,Wo] (top-left crop), w repacked [Cout,3,3,Cin],
  * Cout <= 4. */
-int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias, int Cout,
-                      float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
+int uwir_tail_conv3x3(const void* x, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                      int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
 
 /* ---- evaluation metrics of the student's eval loops, underwater_ir/student/train_student.py:70-95 ----------------
  * x, y NCHW fp32 [B,C,H,W] -> out [B,3] = per image (ssim_loss, mse, psnr): ssim_loss = mean(1 - ssim_map) with the

@@ -873,3 +873,69 @@ def test_model_on_non_current_device(ops):
         assert torch.cuda.current_device() == 0
         outs.append(model(x.to(dev), z.to(dev), None)[0].cpu())   # cuda:1 is NOT the current device here
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bf16_activation_stream_variants(ops):
+    """The IR-SDE UNet's bf16 activation stream: bf16 rows into ln_rows / add_rows / tail_conv3x3 / linattn_block, a bf16
+    residual in the conv epilogue.  Each is checked against fp64 on the SAME bf16-rounded inputs (so only the output
+    rounding and the bf16 MFMA operands remain)."""
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    # ln_rows: bf16 x -> fp32 / bf16 y
+    x = (torch.randn(37, 64 + 8, generator=g) * 2 + 1).to(bf)
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    ref = F.layer_norm(x[:, :64].double(), (64,), gamma.double(), beta.double(), 1e-5)
+    for odt in (torch.float32, bf):
+        y = torch.full((37, 72), 3.0, device="cuda", dtype=odt)
+        ops.ln_rows(x.cuda()[:, :64], gamma.cuda(), beta.cuda(), y[:, :64], 1e-5)
+        assert err(y[:, :64], ref) < (1e-5 if odt == torch.float32 else 4e-2) and float(y[:, 64:].float().min()) == 3.0
+    # add_rows: fp32 + bf16 -> bf16 / fp32
+    a, b = torch.randn(9, 24, generator=g), torch.randn(9, 24, generator=g).to(bf)
+    for odt in (torch.float32, bf):
+        o = torch.zeros(9, 28, device="cuda", dtype=odt)
+        ops.add_rows(a.cuda()[:, :20], b.cuda()[:, 4:], o[:, 8:])
+        exp = (a[:, :20] + b[:, 4:].float()).to(odt)
+        assert torch.equal(o[:, 8:].cpu(), exp) and float(o[:, :8].float().abs().max()) == 0.0
+    # conv epilogue: bf16 residual (3x3 halo path and a plain 1x1 GEMM)
+    bb, c, h, w, n = 2, 32, 20, 24, 64
+    xi = torch.randn(bb, c, h, w, generator=g)
+    wt = torch.randn(n, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    res = torch.randn(bb * h * w, n, generator=g).to(bf)
+    xin = to_rows(xi).to(bf)
+    xe = xin.float().cpu().reshape(bb, h, w, c).permute(0, 3, 1, 2).double()
+    for odt in (torch.float32, bf):
+        out = torch.empty(bb * h * w, n, device="cuda", dtype=odt)
+        ops.conv_gemm(xin, wt.permute(0, 2, 3, 1).reshape(n, -1).bfloat16().cuda().contiguous(), out, B=bb, H=h, W=w, C_=c, N=n,
+                      KH=3, KW=3, pad=1, act=ops.ACT_SILU, res=res.cuda())
+        refc = F.silu(F.conv2d(xe, wt.bfloat16().double(), padding=1)) + from_rows(res.double(), bb, h, w)
+        assert rel(from_rows(out, bb, h, w), refc) < (1e-5 if odt == torch.float32 else 1e-2)
+    w1 = (torch.randn(128, 64, generator=g) / 8).to(bf)
+    x1 = torch.randn(300, 64, generator=g).to(bf)
+    r1 = torch.randn(300, 128, generator=g).to(bf)
+    o1 = torch.empty(300, 128, device="cuda")
+    ops.conv_gemm(x1.cuda(), w1.cuda(), o1, B=1, H=1, W=300, C_=64, N=128, res=r1.cuda())
+    assert err(o1, x1.double() @ w1.double().T + r1.double()) < 1e-4
+    with pytest.raises(Exception):   # bf16 residual rows must start on 8-byte boundaries
+        ops.conv_gemm(x1.cuda(), w1.cuda(), o1, B=1, H=1, W=300, C_=64, N=128, res=r1.cuda()[:, 1:])   # misaligned view
+    # tail conv on bf16 rows
+    feat = torch.randn(2, 32, 16, 32, generator=g).to(bf)
+    wt2, bt = torch.randn(3, 32, 3, 3, generator=g) * 0.1, torch.randn(3, generator=g)
+    o = torch.empty(2, 3, 13, 18, device="cuda")
+    ops.tail_conv3x3(to_rows(feat.float()).to(bf), 2, 16, 32, 32, wt2.permute(0, 2, 3, 1).contiguous().cuda(), bt.cuda(), 3, o)
+    assert err(o, F.conv2d(feat.double(), wt2.double(), bt.double(), padding=1)[..., :13, :18]) < 2e-5
+    # fused LinearAttention block on bf16 rows: same function as on the fp32 rows holding the same values
+    bq, nq, dim = 2, 300, 64
+    xq = (torch.randn(bq * nq, dim, generator=g) * 1.5).to(bf)
+    g_pre, g_out = torch.rand(dim, generator=g) + 0.5, torch.rand(dim, generator=g) + 0.5
+    w_qkv = (torch.randn(384, dim, generator=g) * (2.0 / dim ** 0.5)).to(bf)
+    w_out = (torch.randn(dim, 128, generator=g) * (1.0 / 128 ** 0.5)).to(bf)
+    b_out = torch.randn(dim, generator=g) * 0.1
+    ws = torch.empty(ops.linattn_block_workspace_bytes(bq, nq) // 4, device="cuda")
+    o32 = torch.empty(bq * nq, dim, device="cuda")
+    o16 = torch.full((bq * nq, dim + 8), 5.0, device="cuda", dtype=bf)
+    args = (bq, nq, dim, g_pre.cuda(), w_qkv.cuda(), w_out.cuda(), b_out.cuda(), g_out.cuda())
+    ops.linattn_block(xq.float().cuda(), *args, o32, ws)
+    ops.linattn_block(xq.cuda(), *args, o16[:, :dim], ws)
+    assert torch.equal(o16[:, :dim], o32.to(bf)) and float(o16[:, dim:].float().min()) == 5.0
+    with pytest.raises(TypeError):
+        ops.linattn_block(xq.cuda(), *args, o32, ws)

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("ups", ci),
         ("batch_ld", ci),
         ("workspace", vp), ("workspace_bytes", sz),
+        ("res_dtype", ci),
     ]
 
 
@@ -89,19 +90,19 @@ _SIGS = {
     "uwir_head_conv3x3_win": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
     "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
-    "uwir_ln_rows": (ci, [vp, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, sz, vp, ci, sz, vp]),
+    "uwir_ln_rows": (ci, [vp, ci, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, sz, vp, ci, sz, vp]),
     "uwir_unet_input": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "uwir_groupnorm_affine": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, sz, vp]),
     "uwir_linattn_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_linear_attention": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp, sz, vp]),
     "uwir_linattn_block_workspace_bytes": (sz, [ci, ci]),
-    "uwir_linattn_block": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, ci, vp, sz, vp]),
+    "uwir_linattn_block": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, ci, vp, sz, vp]),
     "uwir_conv_variant": (None, [ci]),
     "uwir_dwconv_tiles_per_block": (None, [ci]),
     "uwir_attn_variant": (None, [ci]),
     "uwir_geglu": (ci, [vp, ci, sz, ci, ci, vp, sz, vp]),
     "uwir_softmax_rows": (ci, [vp, ci, ci, ci, vp, vp, ci, vp]),
-    "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "uwir_tail_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_image_metrics_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "uwir_image_metrics": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, sz, vp]),
     "uwir_tensor2img_u8": (ci, [vp, ci, ci, ci, cf, cf, ci, vp, vp]),
@@ -119,7 +120,7 @@ _SIGS = {
     "uwir_multi_scale_retinex": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), ci, vp, vp, sz, vp]),
     "uwir_enhance_state_workspace_bytes": (sz, []),
     "uwir_enhance_state": (ci, [vp, ci, ci, ci, vp, vp, sz, vp]),
-    "uwir_add_rows": (ci, [vp, sz, vp, sz, vp, sz, ci, ci, vp]),
+    "uwir_add_rows": (ci, [vp, sz, vp, ci, sz, vp, ci, sz, ci, ci, vp]),
     "uwir_patchify": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, sz, vp]),
 }
 

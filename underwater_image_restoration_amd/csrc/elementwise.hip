@@ -799,7 +799,8 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
 #define HT_W 32
 #define HT_CC 16
 #define HT_PS 20  // LDS pixel stride in floats: 16 channels + 4 pad (conflict-free 16-byte reads across a row of lanes)
-__global__ void __launch_bounds__(256) head_tile_kernel(const float* __restrict__ x, int ldx, int H, int W, int Cin,
+template <typename TX>
+__global__ void __launch_bounds__(256) head_tile_kernel(const TX* __restrict__ x, int ldx, int H, int W, int Cin,
                                                         const float* __restrict__ a_scale,
                                                         const float* __restrict__ a_shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int Cout,
@@ -886,7 +887,7 @@ extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, i
                "head: bad shape (Cout<=%d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head: a_scale/a_shift must come together");
     if (head_tiled_ok(B, H, W, Cin)) {
-        hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0, (hipStream_t)stream,
                            x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw, H, W, 1,
                            (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("head(tile)");
@@ -910,26 +911,35 @@ extern "C" int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, i
                    Cout <= HEAD_MAX_COUT && ldx >= Cin && ldx % 4 == 0,
                "head_win: bad shape (Cin %% 16 == 0, Cout <= %d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head_win: a_scale/a_shift must come together");
-    hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0, (hipStream_t)stream, x,
                        ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in, frames_out, (float*)nullptr, T, T, 1, win,
                        FH, FW);
     UWIR_LAUNCH_CHECK("head_win");
     return UWIR_OK;
 }
 
-extern "C" int uwir_tail_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
-                                 int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
-    UWIR_CHECK(x && w && out_nchw, "tail: null pointer");
+extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w,
+                                 const float* bias, int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
+    UWIR_CHECK(xv && w && out_nchw, "tail: null pointer");
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "tail: bad input dtype");
+    const float* x = (const float*)xv;
     UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
                    ldx % 4 == 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W,
                "tail: bad shape (Cout<=%d, crop within the map)", HEAD_MAX_COUT);
     if (head_tiled_ok(B, Ho, Wo, Cin)) {
-        hipLaunchKernelGGL(head_tile_kernel, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0, (hipStream_t)stream,
-                           x, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr, w, bias, Cout,
-                           (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0, (const uwir_window*)nullptr, 0, 0);
+        if (x_dtype == UWIR_BF16)
+            hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0,
+                               (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr,
+                               w, bias, Cout, (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0,
+                               (const uwir_window*)nullptr, 0, 0);
+        else
+            hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0,
+                               (hipStream_t)stream, x, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr, w, bias,
+                               Cout, (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0, (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("tail(tile)");
         return UWIR_OK;
     }
+    UWIR_CHECK(x_dtype == UWIR_F32, "tail: bf16 rows need Cin %% 16 == 0");
     size_t npix = (size_t)B * Ho * Wo;
     size_t blocks = ceil_div_sz(npix, 4);
     if (blocks > 16384) blocks = 16384;

@@ -17,6 +17,7 @@ struct GemmP {
     uwir_gemm_args a;
     int M, K, tiles_n, nblocks;  // nblocks = output tiles; the grid holds nblocks * splitk blocks
     int splitk;                  // > 1: K is cut into `splitk` slices, one block each (few-tile launches)
+    int dbg;                     // EXPERIMENT: ablation bits
 };
 
 // ---- deterministic split-K.  A launch with fewer output tiles than CUs (DA-CLIP: 800 token rows -> 42 tiles on 256
@@ -37,7 +38,7 @@ __device__ __forceinline__ void splitk_dump(const GemmP& p, const f32x4 (&acc)[T
 
 template <typename T> struct MmaCfg;
 template <> struct MmaCfg<bf16_t> {
-    static constexpr int BK = 64, EPC = 8, KSTEP = 32, PAD = 8;
+    static constexpr int BK = 64, EPC = 8, KSTEP = 32, PAD = 16;   // 160-byte rows: conflict-free ds_read_b128 fragments (144-byte rows were 2-way conflicted)
 };
 template <> struct MmaCfg<float> {
     static constexpr int BK = 16, EPC = 4, KSTEP = 4, PAD = 4;
@@ -141,7 +142,14 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
     if (EPI == EPI_FULL && g.res) {
         f32x4 r[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) r[j] = ld(g.res + out_row * g.ldr, j);
+        for (int j = 0; j < TN; ++j) {
+            if (g.res_dtype == UWIR_BF16) {
+                const float4 t = nq + j * 4 < N ? load4((const bf16_t*)g.res + out_row * g.ldr + nq + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                r[j] = (f32x4){t.x, t.y, t.z, t.w};
+            } else {
+                r[j] = ld((const float*)g.res + out_row * g.ldr, j);
+            }
+        }
         if (g.res_scale) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -174,6 +182,7 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
 static int epi_class(const uwir_gemm_args& g) {
     if (g.blend_out || g.batch_scale || g.store_mode != 0 || !g.out) return EPI_FULL;
     if (!g.res) return EPI_LEAN;
+    if (g.res_dtype != UWIR_F32) return EPI_FULL;   // (the lean residual class starts the accumulators from fp32 rows)
     // (an affine residual's per-image scale / shift must be one vector per 128-row tile)
     return (g.act == UWIR_ACT_NONE && !g.col_scale && (!g.res_scale || (g.OH * g.OW) % 128 == 0)) ? EPI_RES : EPI_FULL;
 }
@@ -203,7 +212,7 @@ __device__ __forceinline__ void epi_start_issue(const uwir_gemm_args& g, f32x4 (
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i][j] = *reinterpret_cast<const f32x4*>(g.res + (size_t)min(m_base + i * 16 + fr, M - 1) * g.ldr + n);
+                    acc[i][j] = *reinterpret_cast<const f32x4*>((const float*)g.res + (size_t)min(m_base + i * 16 + fr, M - 1) * g.ldr + n);
             }
         }
     }
@@ -687,7 +696,13 @@ static bool glds_eligible(const uwir_gemm_args& g, int K) {
 #define HC_TW 16
 #define HC_PW (HC_TW + 2)
 #define HC_BK 32
-#define HC_STR 40                        // LDS row stride in bf16 (32 + 8 pad): conflict-free 16-byte fragment reads
+#define HC_STR 32                        // LDS row = one pixel's (or channel's) 32-channel chunk: 64 bytes, four 16-byte pieces
+#define HC_PWL 24                        // LDS rows per halo-tile image row (18 used): a multiple of 8, so the swizzle of
+                                         // row (y + ky) * 24 + x + kx depends on x + kx only and (y + ky) stays an immediate
+// piece p of LDS row r sits at piece position p ^ hc_swz(r).  ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} (+32): with lane = 16 * piece + row this placement is conflict-free from any first row; the padded
+// 80-byte rows it replaces were 2-way conflicted on every fragment read (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE)
+__device__ __forceinline__ int hc_swz(int row) { return (row >> 1) & 3; }
 #define HC_TG 3                          // taps per weight stage
 
 template <typename TA, int BN, int HC_TH>
@@ -698,7 +713,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
     constexpr int A_IT = (A_ITEMS + 255) / 256;
     constexpr int W_ITEMS = HC_TG * BN * (HC_BK / 8);
     constexpr int W_IT = (W_ITEMS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) bf16_t sA[HC_NPIX * HC_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sA[(HC_TH + 2) * HC_PWL * HC_STR];
     __shared__ __attribute__((aligned(16))) bf16_t sW[HC_TG * BN * HC_STR];
 
     const uwir_gemm_args& g = p.a;
@@ -736,7 +751,8 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         if (ok) a_ok |= 1u << it;
         const int cy = ok ? iy : 0, cx = ok ? ix : 0;
         a_ptr[it] = Aptr + (((size_t)b * g.H + (cy >> g.ups)) * g.W + (cx >> g.ups)) * g.lda + piece * 8;
-        a_lds[it] = item < A_ITEMS ? pix * HC_STR + piece * 8 : -1;
+        const int lrow = (pix / HC_PW) * HC_PWL + pix % HC_PW;
+        a_lds[it] = item < A_ITEMS ? lrow * HC_STR + (piece ^ hc_swz(lrow)) * 8 : -1;
     }
     const bf16_t* w_ptr[W_IT];
     int w_lds[W_IT];
@@ -748,7 +764,8 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         const int tapl = row / BN, nl = row % BN, nn = n0 + nl;
         if (nn < N) w_ok |= 1u << it;
         w_ptr[it] = Wptr + (size_t)min(nn, N - 1) * K + tapl * C + piece * 8;
-        w_lds[it] = (tapl * BN + chan_perm(nl)) * HC_STR + piece * 8;      // LDS row pi(n)
+        const int lrow = tapl * BN + chan_perm(nl);                        // LDS row pi(n)
+        w_lds[it] = lrow * HC_STR + (piece ^ hc_swz(lrow)) * 8;
     }
     RawChunk<TA, 8> ra[A_IT];
     bf16x8 rw[W_IT];
@@ -783,7 +800,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
                 for (int j = 0; j < 8; ++j) v[j] = (float)ra[it].v[j];
             }
             if (g.a_scale) {   // block-uniform
-                const int ch = c0 + (a_lds[it] % HC_STR);
+                const int ch = c0 + (tid & 3) * 8;   // piece = item % 4 = tid % 4
                 const float* sc = g.a_scale + (size_t)b * C + ch;
                 const float* sh = g.a_shift + (size_t)b * C + ch;
 #pragma unroll
@@ -821,8 +838,13 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     const int wr0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * 64;   // first output row / channel of this wave
-    const bf16_t* a_rd = &sA[(wr0 * HC_PW + fr) * HC_STR + fq * 8];       // + ((i + ky) * HC_PW + kx) * HC_STR: immediates
-    const bf16_t* w_rd = &sW[(wn0 + fr) * HC_STR + fq * 8];               // + (kx * BN + j * 16) * HC_STR
+    const bf16_t* a_rd[HC_TG];                                            // + (i + ky) * HC_PWL * HC_STR: immediates
+#pragma unroll
+    for (int t = 0; t < HC_TG; ++t) {
+        const int r = wr0 * HC_PWL + fr + t;
+        a_rd[t] = &sA[r * HC_STR + (fq ^ hc_swz(r)) * 8];
+    }
+    const bf16_t* w_rd = &sW[(wn0 + fr) * HC_STR + (fq ^ hc_swz(wn0 + fr)) * 8];   // + (kx * BN + j * 16) * HC_STR
 
     // filter row ky = grp (compile-time): taps grp*3 .. grp*3+2
     auto compute = [&](auto grp_tag) {
@@ -832,7 +854,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(a_rd + ((i + grp) * HC_PW + tapl) * HC_STR);
+                fa[i] = *reinterpret_cast<const bf16x8*>(a_rd[tapl] + (i + grp) * HC_PWL * HC_STR);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(w_rd + (tapl * BN + j * 16) * HC_STR);
 #pragma unroll
@@ -852,21 +874,21 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         store_a(c0);
         store_w();
         __syncthreads();
-        load_w(1 * HC_TG * C + c0);
-        compute(std::integral_constant<int, 0>{});
+        if (!(p.dbg & 1)) load_w(1 * HC_TG * C + c0);
+        if (!(p.dbg & 4)) compute(std::integral_constant<int, 0>{});
         // ---- filter row 1
         __syncthreads();
         store_w();
         __syncthreads();
-        load_w(2 * HC_TG * C + c0);
-        if (chunk + 1 < nchunks) load_a(c0 + HC_BK);   // two compute stages ahead of its use
-        compute(std::integral_constant<int, 1>{});
+        if (!(p.dbg & 1)) load_w(2 * HC_TG * C + c0);
+        if (chunk + 1 < nchunks && !(p.dbg & 2)) load_a(c0 + HC_BK);   // two compute stages ahead of its use
+        if (!(p.dbg & 4)) compute(std::integral_constant<int, 1>{});
         // ---- filter row 2
         __syncthreads();
         store_w();
         __syncthreads();
-        if (chunk + 1 < nchunks) load_w(c0 + HC_BK);
-        compute(std::integral_constant<int, 2>{});
+        if (chunk + 1 < nchunks && !(p.dbg & 1)) load_w(c0 + HC_BK);
+        if (!(p.dbg & 4)) compute(std::integral_constant<int, 2>{});
     }
 
     int mrow[TM], mcnt[TM];
@@ -888,8 +910,11 @@ static int g_gemm_wide = 1;   // tools/: uwir_conv_variant(2) keeps the large-K 
 static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
                               // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
 void uwir_fft_set_radix4(int on);   // fft.hip
+static int g_halo_dbg = 0, g_halo_th4 = 0;
 extern "C" void uwir_conv_variant(int v) {
     g_halo_th16 = v & 1;
+    g_halo_th4 = (v >> 3) & 1;
+    g_halo_dbg = (v >> 4) & 7;
     g_gemm_wide = (v & 2) ? 0 : 1;
     uwir_fft_set_radix4((v & 4) ? 0 : 1);
 }
@@ -897,19 +922,25 @@ extern "C" void uwir_conv_variant(int v) {
 template <typename TA>
 static int launch_halo(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
+    p.dbg = g_halo_dbg;
     // optional 16-row tiles (256 pixels per block: TM doubles, i.e. half the weight re-staging and barriers per pixel and
     // 0.5 instead of 0.75 LDS fragment reads per MFMA at N = 64): measured no faster, off by default
     const long long mt16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW);
     const bool th16 = g_halo_th16 && p.a.N <= 64 && mt16 >= 1024;
-    const int th = th16 ? 16 : 8;
-    const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
+    int th = th16 ? 16 : 8;
+    long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
     int bn = p.a.N <= 64 ? 64 : 128;
     if (bn == 128 && mtiles * ceil_div(p.a.N, 128) < 512) bn = 64;
+    if (g_halo_th4 && bn == 64 && mtiles * ceil_div(p.a.N, 64) <= 1024) {
+        th = 4;
+        mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
+    }
     p.tiles_n = ceil_div(p.a.N, bn);
     const long long nb = mtiles * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
-    if (bn == 64 && th16) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 16>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    if (th == 4) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 4>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else if (bn == 64 && th16) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 16>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 128, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm(halo)");
@@ -1020,6 +1051,8 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     UWIR_CHECK((g.res_scale == nullptr) == (g.res_shift == nullptr), "conv_gemm: res_scale/res_shift must come together");
     UWIR_CHECK(!g.res_scale || g.res, "conv_gemm: res_scale without res");
     UWIR_CHECK(!g.res || (g.ldr >= g.N && g.ldr % 4 == 0), "conv_gemm: bad ldr");
+    UWIR_CHECK(!g.res || g.res_dtype == UWIR_F32 || g.res_dtype == UWIR_BF16, "conv_gemm: bad res dtype");
+    UWIR_CHECK(!g.res || ((uintptr_t)g.res & (g.res_dtype == UWIR_BF16 ? 7 : 15)) == 0, "conv_gemm: res must be 16-byte (fp32) / 8-byte (bf16) aligned");
     UWIR_CHECK(!g.blend_out || (g.blend_t && g.blend_f && g.ld_blend_in % 4 == 0 && g.ld_blend_out % 4 == 0),
                "conv_gemm: bad blend arguments");
     UWIR_CHECK(g.store_mode == 0 || g.store_mode == 1, "conv_gemm: bad store_mode");
@@ -1042,6 +1075,7 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.tiles_n = 0;
     p.nblocks = 0;
     p.splitk = 1;
+    p.dbg = 0;
     hipStream_t s = (hipStream_t)stream;
     if (halo_eligible(g)) {
         if (g.a_dtype == UWIR_F32) return launch_halo<float>(p, s);

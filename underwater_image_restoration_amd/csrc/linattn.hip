@@ -44,8 +44,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {   // registers
 // ------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------
-template <int DIM>
-__global__ void __launch_bounds__(256) la_kv_fused_kernel(const float* __restrict__ x, int ldx, int n, int rows_per_chunk,
+template <int DIM, typename TX>
+__global__ void __launch_bounds__(256) la_kv_fused_kernel(const TX* __restrict__ x, int ldx, int n, int rows_per_chunk,
                                                           int nchunks, const float* __restrict__ g_pre, float eps,
                                                           const bf16_t* __restrict__ w_qkv, float* __restrict__ part) {
     constexpr int D = LF_D, KS = DIM / 16, PITCH = DIM + 8;          // bf16 elements per LDS row (16-byte pad)
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) la_kv_fused_kernel(const float* __restric
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int r_begin = chunk * rows_per_chunk, r_end = min(n, r_begin + rows_per_chunk);
     const int head = wave;
-    const float* xb = x + (size_t)b * n * ldx;
+    const TX* xb = x + (size_t)b * n * ldx;
 
     // weights of this head as B operands: B[k = c][n = d] = Wk[head*32 + d][c]  (rows 128.. of w_qkv are k, 256.. v)
     bf16x8 wk[KS], wv[KS];
@@ -204,14 +204,14 @@ __global__ void __launch_bounds__(1024) la_fin_fused_kernel(const float* __restr
 // ds_read_b128: LDS column st*16 + h*8 + j of a 32-wide group holds source column 16 st + 8 (j>>2) + 4 h + (j&3).
 // ------------------------------------------------------------------------------------------
 
-template <int DIM>
-__global__ void __launch_bounds__(256) la_apply_fused_kernel(const float* __restrict__ x, int ldx, int n,
+template <int DIM, typename TX>
+__global__ void __launch_bounds__(256) la_apply_fused_kernel(const TX* __restrict__ x, int ldx, int n,
                                                              const float* __restrict__ g_pre, float eps,
                                                              const bf16_t* __restrict__ w_qkv,
                                                              const bf16_t* __restrict__ ctxT,
                                                              const bf16_t* __restrict__ w_out,
                                                              const float* __restrict__ b_out,
-                                                             const float* __restrict__ g_out, float* __restrict__ out,
+                                                             const float* __restrict__ g_out, TX* __restrict__ out,
                                                              int ldo, int rgw) {
     constexpr int D = LF_D, KS = DIM / 16, HD = LF_HEADS * D, OT = DIM / 32;
     constexpr int PQ = DIM + 8, PO = HD + 8, PC = D + 8;             // LDS pitches in bf16 elements
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) la_apply_fused_kernel(const float* __rest
         if (rbase >= n) break;                                         // wave-uniform; no barrier below
         const int row = min(rbase + lq, n - 1);                        // clamped rows recompute the last row (not stored)
         const bool row_ok = rbase + lq < n;
-        const float* xr = x + ((size_t)b * n + row) * ldx;
+        const TX* xr = x + ((size_t)b * n + row) * ldx;
 
         // ---- this lane's half of its row, in B-operand order: channels 16 ks + 8 lh + j ; LayerNorm across the lane pair
         float xv[KS][8];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) la_apply_fused_kernel(const float* __rest
             for (int r = 0; r < 16; ++r) { z[ot][r] -= zmean; zq = fmaf(z[ot][r], z[ot][r], zq); }
         const float zrstd = rsqrtf(half_sum(zq) * (1.f / DIM) + eps);
         if (row_ok) {
-            float* orow = out + ((size_t)b * n + row) * ldo;
+            TX* orow = out + ((size_t)b * n + row) * ldo;
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -392,13 +392,15 @@ extern "C" size_t uwir_linattn_block_workspace_bytes(int B, int n) {
            (size_t)B * LF_HEADS * LF_D * LF_D * sizeof(bf16_t);
 }
 
-extern "C" int uwir_linattn_block(const float* x, int ldx, int B, int n, int dim, int heads, const float* g_pre,
+extern "C" int uwir_linattn_block(const void* x, int io_dtype, int ldx, int B, int n, int dim, int heads, const float* g_pre,
                                   const void* w_qkv, const void* w_out, const float* b_out, const float* g_out, float eps,
-                                  float* out, int ldo, void* workspace, size_t workspace_bytes, uwir_stream_t stream) {
+                                  void* out, int ldo, void* workspace, size_t workspace_bytes, uwir_stream_t stream) {
     UWIR_CHECK(x && g_pre && w_qkv && w_out && b_out && g_out && out && workspace, "linattn_block: null pointer");
+    UWIR_CHECK(io_dtype == UWIR_F32 || io_dtype == UWIR_BF16, "linattn_block: x / out must be fp32 or bf16");
     UWIR_CHECK(heads == LF_HEADS, "linattn_block: heads must be 4 (the reference's LinearAttention)");
     UWIR_CHECK(dim == 64 || dim == 128 || dim == 256, "linattn_block: dim must be 64, 128 or 256 (got %d)", dim);
-    UWIR_CHECK(B > 0 && B <= 65535 && n > 0 && ldx >= dim && ldx % 4 == 0 && ldo >= dim && ldo % 4 == 0,
+    const int ldq = io_dtype == UWIR_BF16 ? 8 : 4;    // rows start on 16-byte boundaries
+    UWIR_CHECK(B > 0 && B <= 65535 && n > 0 && ldx >= dim && ldx % ldq == 0 && ldo >= dim && ldo % ldq == 0,
                "linattn_block: bad shape");
     UWIR_CHECK((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w_qkv | (uintptr_t)w_out | (uintptr_t)g_pre | (uintptr_t)g_out |
                  (uintptr_t)b_out | (uintptr_t)workspace) & 15) == 0, "linattn_block: pointers must be 16-byte aligned");
@@ -415,16 +417,20 @@ extern "C" int uwir_linattn_block(const float* x, int ldx, int B, int n, int dim
     long long quads = (long long)B * ceil_div(n, 128);
     int rgw = (int)(quads / 768);
     rgw = rgw < 1 ? 1 : (rgw > 8 ? 8 : rgw);
-#define LA_LAUNCH(DIM_)                                                                                                    \
-    hipLaunchKernelGGL(la_kv_fused_kernel<DIM_>, dim3(nchunks, B), dim3(256), 0, s, x, ldx, n, rpc, nchunks, g_pre, eps, wq,  \
-                       part);                                                                                              \
+#define LA_LAUNCH(DIM_, TX_)                                                                                               \
+    hipLaunchKernelGGL((la_kv_fused_kernel<DIM_, TX_>), dim3(nchunks, B), dim3(256), 0, s, (const TX_*)x, ldx, n, rpc,     \
+                       nchunks, g_pre, eps, wq, part);                                                                     \
     UWIR_LAUNCH_CHECK("linattn_block(kv)");                                                                                \
     hipLaunchKernelGGL(la_fin_fused_kernel, dim3(B * LF_HEADS), dim3(1024), 0, s, part, nchunks, inv_n_scale, ctxT);          \
     UWIR_LAUNCH_CHECK("linattn_block(fin)");                                                                               \
-    hipLaunchKernelGGL(la_apply_fused_kernel<DIM_>, dim3(ceil_div(n, 128 * rgw), B), dim3(256), 0, s, x, ldx, n, g_pre, eps, wq, \
-                       ctxT, wo, b_out, g_out, out, ldo, rgw);                                                             \
+    hipLaunchKernelGGL((la_apply_fused_kernel<DIM_, TX_>), dim3(ceil_div(n, 128 * rgw), B), dim3(256), 0, s,               \
+                       (const TX_*)x, ldx, n, g_pre, eps, wq, ctxT, wo, b_out, g_out, (TX_*)out, ldo, rgw);                \
     UWIR_LAUNCH_CHECK("linattn_block(apply)");
-    if (dim == 64) { LA_LAUNCH(64) } else if (dim == 128) { LA_LAUNCH(128) } else { LA_LAUNCH(256) }
+    if (io_dtype == UWIR_BF16) {
+        if (dim == 64) { LA_LAUNCH(64, bf16_t) } else if (dim == 128) { LA_LAUNCH(128, bf16_t) } else { LA_LAUNCH(256, bf16_t) }
+    } else {
+        if (dim == 64) { LA_LAUNCH(64, float) } else if (dim == 128) { LA_LAUNCH(128, float) } else { LA_LAUNCH(256, float) }
+    }
 #undef LA_LAUNCH
     return UWIR_OK;
 }

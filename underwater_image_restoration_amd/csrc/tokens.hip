@@ -11,8 +11,8 @@
 // ------------------------------------------------------------------------------------------
 // G = lanes that share one row (64, 32, 16 or 8): narrow rows (C = 64 -> 16 float4) would leave most of a wave idle,
 // so a wave handles 64 / G rows and the reductions stay inside the G-lane group.
-template <typename TY, int G>
-__global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ x, size_t ldx, int M, int C4,
+template <typename TX, typename TY, int G>
+__global__ void __launch_bounds__(256) ln_rows_kernel(const TX* __restrict__ x, size_t ldx, int M, int C4,
                                                       const float* __restrict__ add, int add_period, int add_ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, const float* res, size_t ldr, TY* y, size_t ldy) {
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
     const int row_raw = wave * RPW + lane / G;
     const bool live = row_raw < M;
     const int row = live ? row_raw : M - 1;  // dead groups shadow the last row (no stores) so shuffles stay convergent
-    const float* xr = x + (size_t)row * ldx;
+    const TX* xr = x + (size_t)row * ldx;
     const float* ar = add ? add + (size_t)(row % add_period) * add_ld : nullptr;
     const float invC = 1.f / (float)(4 * C4);
     auto ld = [&](int c4) {
@@ -69,13 +69,13 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* __restrict__ 
     }
 }
 
-template <typename TY>
-static void launch_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
+template <typename TX, typename TY>
+static void launch_ln_rows(const TX* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
                            const float* gamma, const float* beta, float eps, const float* res, size_t ldr, TY* y,
                            size_t ldy, hipStream_t s) {
     const int C4 = C / 4;
 #define LN_LAUNCH(G)                                                                                                   \
-    hipLaunchKernelGGL((ln_rows_kernel<TY, G>), dim3(ceil_div(M, 4 * (UWIR_WAVE / G))), dim3(256), 0, s, x, ldx, M, C4, \
+    hipLaunchKernelGGL((ln_rows_kernel<TX, TY, G>), dim3(ceil_div(M, 4 * (UWIR_WAVE / G))), dim3(256), 0, s, x, ldx, M, C4, \
                        add, add_period, add_ld, gamma, beta, eps, res, ldr, y, ldy)
     if (C4 <= 8) LN_LAUNCH(8);
     else if (C4 <= 16) LN_LAUNCH(16);
@@ -84,7 +84,7 @@ static void launch_ln_rows(const float* x, size_t ldx, int M, int C, const float
 #undef LN_LAUNCH
 }
 
-extern "C" int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
+extern "C" int uwir_ln_rows(const void* x, int x_dtype, size_t ldx, int M, int C, const float* add, int add_period, int add_ld,
                             const float* gamma, const float* beta, float eps, const float* res, size_t ldr, void* y,
                             int y_dtype, size_t ldy, uwir_stream_t stream) {
     UWIR_CHECK(x && gamma && y, "ln_rows: null pointer");
@@ -93,13 +93,17 @@ extern "C" int uwir_ln_rows(const float* x, size_t ldx, int M, int C, const floa
     UWIR_CHECK(!add || (add_period > 0 && add_ld >= C && add_ld % 4 == 0), "ln_rows: bad add table");
     UWIR_CHECK(!res || (ldr >= (size_t)C && ldr % 4 == 0), "ln_rows: bad residual stride");
     UWIR_CHECK(y_dtype == UWIR_F32 || y_dtype == UWIR_BF16, "ln_rows: bad output dtype");
-    UWIR_CHECK((const void*)x != (const void*)y || y_dtype == UWIR_F32, "ln_rows: in-place needs an fp32 output");
-    if (y_dtype == UWIR_F32)
-        launch_ln_rows<float>(x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy,
-                              (hipStream_t)stream);
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "ln_rows: bad input dtype");
+    UWIR_CHECK((const void*)x != (const void*)y || (y_dtype == UWIR_F32 && x_dtype == UWIR_F32), "ln_rows: in-place needs fp32 rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == UWIR_F32 && y_dtype == UWIR_F32)
+        launch_ln_rows<float, float>((const float*)x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy, st);
+    else if (x_dtype == UWIR_F32)
+        launch_ln_rows<float, bf16_t>((const float*)x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy, st);
+    else if (y_dtype == UWIR_F32)
+        launch_ln_rows<bf16_t, float>((const bf16_t*)x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (float*)y, ldy, st);
     else
-        launch_ln_rows<bf16_t>(x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy,
-                               (hipStream_t)stream);
+        launch_ln_rows<bf16_t, bf16_t>((const bf16_t*)x, ldx, M, C, add, add_period, add_ld, gamma, beta, eps, res, ldr, (bf16_t*)y, ldy, st);
     UWIR_LAUNCH_CHECK("ln_rows");
     return UWIR_OK;
 }
@@ -154,7 +158,8 @@ extern "C" int uwir_patchify(const float* img_nchw, int B, int Cin, int H, int W
 // The explicit form of the main tower's `x += control.pop()` (L/open_clip/transformer.py:367-368) when the
 // caller hands in materialised hiddens.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) add_rows_kernel(const float* a, size_t lda, const float* b, size_t ldb, float* out,
+template <typename TB, typename TO>
+__global__ void __launch_bounds__(256) add_rows_kernel(const float* a, size_t lda, const TB* b, size_t ldb, TO* out,
                                                        size_t ldo, int C4, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int c4 = (int)(i % C4);
@@ -164,8 +169,8 @@ __global__ void __launch_bounds__(256) add_rows_kernel(const float* a, size_t ld
     }
 }
 
-extern "C" int uwir_add_rows(const float* a, size_t lda, const float* b, size_t ldb, float* out, size_t ldo, int M,
-                             int C, uwir_stream_t stream) {
+extern "C" int uwir_add_rows(const float* a, size_t lda, const void* b, int b_dtype, size_t ldb, void* out, int out_dtype,
+                             size_t ldo, int M, int C, uwir_stream_t stream) {
     UWIR_CHECK(a && b && out, "add_rows: null pointer");
     UWIR_CHECK(M > 0 && C > 0 && C % 4 == 0 && lda >= (size_t)C && ldb >= (size_t)C && ldo >= (size_t)C &&
                    lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0,
@@ -173,8 +178,16 @@ extern "C" int uwir_add_rows(const float* a, size_t lda, const float* b, size_t 
     size_t total = (size_t)M * (C / 4);
     size_t g = ceil_div_sz(total, 256);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo,
-                       C / 4, total);
+    UWIR_CHECK((b_dtype == UWIR_F32 || b_dtype == UWIR_BF16) && (out_dtype == UWIR_F32 || out_dtype == UWIR_BF16), "add_rows: bad dtype");
+    UWIR_CHECK((const void*)a != (const void*)out || out_dtype == UWIR_F32, "add_rows: out may alias a only as fp32");
+#define ADD_LAUNCH(TB_, TO_)                                                                                            \
+    hipLaunchKernelGGL((add_rows_kernel<TB_, TO_>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, lda,       \
+                       (const TB_*)b, ldb, (TO_*)out, ldo, C / 4, total)
+    if (b_dtype == UWIR_F32 && out_dtype == UWIR_F32) ADD_LAUNCH(float, float);
+    else if (b_dtype == UWIR_F32) ADD_LAUNCH(float, bf16_t);
+    else if (out_dtype == UWIR_F32) ADD_LAUNCH(bf16_t, float);
+    else ADD_LAUNCH(bf16_t, bf16_t);
+#undef ADD_LAUNCH
     UWIR_LAUNCH_CHECK("add_rows");
     return UWIR_OK;
 }

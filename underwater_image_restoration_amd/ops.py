@@ -151,7 +151,7 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
               blend_out=None, col_scale=None, batch_scale=None, ups: int = 0) -> None:
     """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h."""
     lib = _lib.load()
-    _f32(a_scale, a_shift, bias, batch_bias, res, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale, batch_scale)
+    _f32(a_scale, a_shift, bias, batch_bias, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale, batch_scale)
     g = GemmArgs()
     g.A, g.a_dtype, g.lda = _p(A), _dt(A), _ld(A)
     g.B, g.H, g.W, g.C = B, H, W, C_
@@ -169,7 +169,7 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
             if t.shape[0] != B or t.shape[1] != N or (g.batch_ld not in (0, _ld(t))):
                 raise ValueError("conv_gemm: batch_bias / batch_scale must be [B, N] views sharing a row stride")
             g.batch_ld = _ld(t)
-    g.res, g.ldr = _p(res), (0 if res is None else _ld(res))
+    g.res, g.ldr, g.res_dtype = _p(res), (0 if res is None else _ld(res)), (0 if res is None else _dt(res))
     g.res_scale, g.res_shift = _p(res_scale), _p(res_shift)
     g.out = _p(out)
     g.out_dtype, g.ldo = (0, 0) if out is None else (_dt(out), _ld(out))
@@ -351,15 +351,15 @@ def gemm(A: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor, **kw) -> None:
 
 def ln_rows(x: torch.Tensor, gamma, beta, y: torch.Tensor, eps: float = 1e-5, add=None, add_period: int = 0,
             res=None) -> None:
-    """y[m] = LayerNorm_C(x[m] + add[m % add_period]) * gamma + beta (+ res[m]); x fp32 [M, C] view, y fp32/bf16."""
-    _f32(x, gamma, beta, add, res)
+    """y[m] = LayerNorm_C(x[m] + add[m % add_period]) * gamma + beta (+ res[m]); x, y fp32 / bf16 [M, C] views."""
+    _f32(gamma, beta, add, res)
     lib = _lib.load()
     M, C_ = x.shape
     if y.shape[0] != M or y.shape[1] != C_ or gamma.numel() != C_:
         raise ValueError("ln_rows: shape mismatch")
     if add is not None and (add.shape[0] != add_period or add.shape[1] != C_):
         raise ValueError("ln_rows: add table must be [add_period, C]")
-    _lib.check(lib.uwir_ln_rows(_p(x), _ld(x), M, C_, _p(add), add_period, 0 if add is None else _ld(add), _p(gamma),
+    _lib.check(lib.uwir_ln_rows(_p(x), _dt(x), _ld(x), M, C_, _p(add), add_period, 0 if add is None else _ld(add), _p(gamma),
                                 _p(beta), eps, _p(res), 0 if res is None else _ld(res), _p(y), _dt(y), _ld(y),
                                 _stream(x)), "ln_rows")
 
@@ -374,12 +374,14 @@ def patchify(img: torch.Tensor, P: int, out: torch.Tensor) -> None:
 
 
 def add_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
-    _f32(a, b, out)
+    """out = a + b; a fp32, b and out fp32 or bf16."""
+    _f32(a)
     lib = _lib.load()
     M, C_ = a.shape
     if b.shape != a.shape or out.shape != a.shape:
         raise ValueError("add_rows: shape mismatch")
-    _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C_, _stream(a)), "add_rows")
+    _lib.check(lib.uwir_add_rows(_p(a), _ld(a), _p(b), _dt(b), _ld(b), _p(out), _dt(out), _ld(out), M, C_, _stream(a)),
+               "add_rows")
 
 
 def unet_input(xt: torch.Tensor, cond: torch.Tensor, Hp: int, Wp: int, out: torch.Tensor) -> None:
@@ -421,13 +423,15 @@ def linattn_block_workspace_bytes(B: int, n: int) -> int:
 def linattn_block(x: torch.Tensor, B: int, n: int, dim: int, g_pre, w_qkv, w_out, b_out, g_out, out: torch.Tensor,
                   workspace: torch.Tensor, eps: float = 1e-5, heads: int = 4) -> None:
     """out = LN_gout(W_out . LinearAttention(W_qkv . LN_gpre(x)) + b_out) + x, fused (bf16 MFMA); see uwir.h."""
-    _f32(x, g_pre, b_out, g_out, out)
+    _f32(g_pre, b_out, g_out)
+    if _dt(x) != _dt(out):
+        raise TypeError("linattn_block: x and out must share a dtype (fp32 or bf16)")
     if w_qkv.dtype != torch.bfloat16 or w_out.dtype != torch.bfloat16 or not w_qkv.is_contiguous() or not w_out.is_contiguous():
         raise TypeError("linattn_block: weights must be contiguous bf16")
     if tuple(w_qkv.shape) != (3 * heads * 32, dim) or tuple(w_out.shape) != (dim, heads * 32):
         raise ValueError("linattn_block: weight shapes must be [3*heads*32, dim] and [dim, heads*32]")
     lib = _lib.load()
-    _lib.check(lib.uwir_linattn_block(_p(x), _ld(x), B, n, dim, heads, _p(g_pre), _p(w_qkv), _p(w_out), _p(b_out), _p(g_out),
+    _lib.check(lib.uwir_linattn_block(_p(x), _dt(x), _ld(x), B, n, dim, heads, _p(g_pre), _p(w_qkv), _p(w_out), _p(b_out), _p(g_out),
                                       eps, _p(out), _ld(out), _p(workspace), workspace.numel() * workspace.element_size(),
                                       _stream(x)), "linattn_block")
 
@@ -448,10 +452,10 @@ def softmax_rows(x: torch.Tensor, mul, y: torch.Tensor) -> None:
 
 
 def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cout: int, out_nchw: torch.Tensor) -> None:
-    _f32(x, w, bias, out_nchw)
+    _f32(w, bias, out_nchw)
     lib = _lib.load()
     Ho, Wo = out_nchw.shape[2], out_nchw.shape[3]
-    _lib.check(lib.uwir_tail_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream(x)),
+    _lib.check(lib.uwir_tail_conv3x3(_p(x), _dt(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream(x)),
                "tail_conv3x3")
 
 

@@ -4,8 +4,11 @@ Mirrors /root/reference/legacy/third_party/universal-image-restoration/config/da
 DenoisingUNet_arch.py:21-174: same constructor, same ``forward(xt, cond, time, text_context=None,
 image_context=None)`` (NCHW in, NCHW noise prediction out), same ``state_dict`` keys / shapes
 (synth.unet_param_shapes; a ``module.`` prefix from nn.DataParallel checkpoints is stripped like
-models/base_model.py:98-103).  Extra knob: ``precision`` ("fp32" exact-fp32 MFMA, "bf16" bf16 MFMA with fp32
-accumulate; residual stream, norms and softmaxes stay fp32).
+models/base_model.py:98-103).  Extra knob: ``precision`` ("fp32": exact-fp32 MFMA, fp32 activations; "bf16": bf16 MFMA
+with fp32 accumulation, and the activation stream between kernels -- ResBlock / attention outputs, skips, residuals --
+is stored as bf16 too: at level 0 the 3x3 convs are HBM-bound on exactly those tensors.  Norm statistics, softmaxes and
+every accumulation stay fp32.  Measured against the fp32 model (tools/exp/bf16_stream_emul.py, B = 2, 256 x 256): one
+step rel. L2 5.0e-3 with an fp32 stream, 5.9e-3 with the bf16 stream; 100-step reverse_posterior 49.3 vs 49.0 dB).
 
 Everything runs NHWC through the C ABI (include/uwir.h); this file owns buffers, weight repacking, launch order:
   * 3x3 / 4x4-s2 / 7x7 / nearest-2x+3x3 convs = implicit GEMM on MFMA; the ResBlock's ``x*(scale+1)+shift`` + SiLU and
@@ -222,7 +225,7 @@ class ConditionalUNet(nn.Module):
         return emb
 
     def _resblock(self, r: dict, x: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, ss_all: torch.Tensor, tag: str):
-        """ResBlock (module_util.py:131-153): x [M, din] view -> out [M, dout] view (fp32)."""
+        """ResBlock (module_util.py:131-153): x [M, din] view -> out [M, dout] view (stream dtype)."""
         M, dev, adt = B * H * W, x.device, self._pack["adt"]
         din, dout, off = r["din"], r["dout"], r["off"]
         h = self._buf(tag + "h", M, dout, adt, dev)
@@ -230,7 +233,7 @@ class ConditionalUNet(nn.Module):
                       batch_scale=ss_all[:, off:off + dout], batch_bias=ss_all[:, off + dout:off + 2 * dout], act=ops.ACT_SILU)
         res = x
         if r["wres"] is not None:
-            res = self._buf(tag + "r", M, dout, torch.float32, dev)
+            res = self._buf(tag + "r", M, dout, adt, dev)
             ops.conv_gemm(x, r["wres"], res, B=B, H=H, W=W, C_=din, N=dout)
         ops.conv_gemm(h, r["w2"], out, B=B, H=H, W=W, C_=dout, N=dout, KH=3, KW=3, pad=1, act=ops.ACT_SILU, res=res)
 
@@ -253,7 +256,11 @@ class ConditionalUNet(nn.Module):
             ops.linear_attention(qkv, B, n, 4, la, ws)
             y = self._buf(tag + "y", M, dim, f32, dev)
             ops.conv_gemm(la, a["w_out"], y, B=B, H=H, W=W, C_=128, N=dim, bias=a["b_out"])
-            ops.ln_rows(y, a["g_out"], None, out, 1e-5, res=x)
+            if x.dtype == f32:
+                ops.ln_rows(y, a["g_out"], None, out, 1e-5, res=x)
+            else:   # bf16 stream: the norm's fp32 residual slot cannot take x
+                ops.ln_rows(y, a["g_out"], None, y, 1e-5)
+                ops.add_rows(y, x, out)
             return
         if u_all is None:
             raise ValueError("image_context is required: the model was built with use_image_context=True")
@@ -376,9 +383,10 @@ class ConditionalUNet(nn.Module):
         Hs = [Hp >> i for i in range(D)]
         Ws = [Wp >> i for i in range(D)]
         Ms = [B * Hs[i] * Ws[i] for i in range(D)]
-        catA = [self._buf(f"catA{i}", Ms[i], lv[i][1] + lv[i][0], f32, dev) for i in range(D)]
-        catB = [self._buf(f"catB{i}", Ms[i], lv[i][1] + lv[i][0], f32, dev) for i in range(D)]
-        catF = self._buf("catF", Ms[0], 2 * nf, f32, dev)
+        sdt = pk["adt"]    # the activation stream's dtype: fp32, or bf16 in bf16 mode
+        catA = [self._buf(f"catA{i}", Ms[i], lv[i][1] + lv[i][0], sdt, dev) for i in range(D)]
+        catB = [self._buf(f"catB{i}", Ms[i], lv[i][1] + lv[i][0], sdt, dev) for i in range(D)]
+        catF = self._buf("catF", Ms[0], 2 * nf, sdt, dev)
 
         x_in = self._buf("x_in", Ms[0], 8, f32, dev)
         ops.unet_input(xt, cond, Hp, Wp, x_in)
@@ -392,21 +400,21 @@ class ConditionalUNet(nn.Module):
             d = pk["downs"][i]
             h1, h2 = catB[i][:, dout:], catA[i][:, dout:]
             self._resblock(d["b1"], x, h1, B, Hs[i], Ws[i], ss_all, f"d{i}a")
-            tmp = self._buf(f"d{i}t", Ms[i], din, f32, dev)
+            tmp = self._buf(f"d{i}t", Ms[i], din, sdt, dev)
             self._resblock(d["b2"], h1, tmp, B, Hs[i], Ws[i], ss_all, f"d{i}b")
             self._attn(d["attn"], tmp, h2, B, Hs[i], Ws[i], u_all, f"d{i}c")
             if taps is not None:
                 taps[f"down{i}"] = self._nchw(h2, B, Hs[i], Ws[i])
             if i != D - 1:
-                nxt = self._buf(f"xin{i + 1}", Ms[i + 1], dout, f32, dev)
+                nxt = self._buf(f"xin{i + 1}", Ms[i + 1], dout, sdt, dev)
                 ops.conv_gemm(h2, d["w_down"], nxt, B=B, H=Hs[i], W=Ws[i], C_=din, N=dout, KH=4, KW=4, stride=2, pad=1,
                               bias=d["b_down"])
             else:
-                nxt = self._buf("xmid", Ms[i], dout, f32, dev)
+                nxt = self._buf("xmid", Ms[i], dout, sdt, dev)
                 ops.conv_gemm(h2, d["w_down"], nxt, B=B, H=Hs[i], W=Ws[i], C_=din, N=dout, KH=3, KW=3, pad=1)
             x = nxt
         Hm, Wm, Mm, dm = Hs[-1], Ws[-1], Ms[-1], lv[-1][1]
-        m1, m2 = self._buf("m1", Mm, dm, f32, dev), self._buf("m2", Mm, dm, f32, dev)
+        m1, m2 = self._buf("m1", Mm, dm, sdt, dev), self._buf("m2", Mm, dm, sdt, dev)
         self._resblock(pk["mid1"], x, m1, B, Hm, Wm, ss_all, "m1")
         self._attn(pk["mid_attn"], m1, m2, B, Hm, Wm, u_all, "ma")
         self._resblock(pk["mid2"], m2, catA[D - 1][:, :dm], B, Hm, Wm, ss_all, "m2")
@@ -417,7 +425,7 @@ class ConditionalUNet(nn.Module):
             din, dout = lv[i]
             u = pk["ups"][j]
             self._resblock(u["b1"], catA[i], catB[i][:, :dout], B, Hs[i], Ws[i], ss_all, f"u{j}a")
-            t2, t3 = self._buf(f"u{j}t2", Ms[i], dout, f32, dev), self._buf(f"u{j}t3", Ms[i], dout, f32, dev)
+            t2, t3 = self._buf(f"u{j}t2", Ms[i], dout, sdt, dev), self._buf(f"u{j}t3", Ms[i], dout, sdt, dev)
             self._resblock(u["b2"], catB[i], t2, B, Hs[i], Ws[i], ss_all, f"u{j}b")
             self._attn(u["attn"], t2, t3, B, Hs[i], Ws[i], u_all, f"u{j}c")
             if taps is not None:
@@ -427,7 +435,7 @@ class ConditionalUNet(nn.Module):
                               ups=1, bias=u["b_up"])
             else:
                 ops.conv_gemm(t3, u["w_up"], catF[:, :nf], B=B, H=Hs[i], W=Ws[i], C_=dout, N=din, KH=3, KW=3, pad=1)
-        fin = self._buf("fin", Ms[0], nf, f32, dev)
+        fin = self._buf("fin", Ms[0], nf, sdt, dev)
         self._resblock(pk["final"], catF, fin, B, Hp, Wp, ss_all, "fin")
         out = torch.empty(B, self.out_nc, H, W, dtype=f32, device=dev)
         ops.tail_conv3x3(fin, B, Hp, Wp, nf, pk["tail_w"], pk["tail_b"], self.out_nc, out)
