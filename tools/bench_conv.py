@@ -11,14 +11,15 @@ from underwater_image_restoration_amd import _lib, ops  # noqa: E402
 f32, bf = torch.float32, torch.bfloat16
 # (H, C, N, k, a dtype, out dtype, residual, ups)
 SHAPES = (
-    (256, 64, 64, 3, f32, bf, False, 0), (256, 64, 64, 3, bf, f32, True, 0), (256, 128, 64, 3, f32, bf, False, 0),
-    (256, 128, 64, 1, f32, f32, False, 0),
-    (128, 64, 64, 3, f32, bf, False, 0), (128, 64, 64, 3, bf, f32, True, 0), (128, 192, 128, 3, f32, bf, False, 0),
-    (128, 128, 128, 3, bf, f32, True, 0),
-    (64, 128, 128, 3, f32, bf, False, 0), (64, 128, 128, 3, bf, f32, True, 0), (64, 384, 256, 3, f32, bf, False, 0),
-    (64, 256, 256, 3, bf, f32, True, 0),
-    (32, 256, 256, 3, f32, bf, False, 0), (32, 256, 256, 3, bf, f32, True, 0), (32, 512, 512, 3, f32, bf, False, 0),
-    (32, 512, 512, 3, bf, f32, True, 0), (32, 768, 512, 3, f32, bf, False, 0), (32, 512, 256, 3, f32, f32, False, 1),
+    (256, 64, 64, 3, bf, bf, False, 0), (256, 64, 64, 3, bf, bf, True, 0), (256, 128, 64, 3, bf, bf, False, 0),
+    (256, 128, 64, 1, bf, bf, False, 0),
+    (128, 64, 64, 3, bf, bf, False, 0), (128, 64, 64, 3, bf, bf, True, 0), (128, 192, 128, 3, bf, bf, False, 0),
+    (128, 128, 128, 3, bf, bf, True, 0),
+    (64, 128, 128, 3, bf, bf, False, 0), (64, 128, 128, 3, bf, bf, True, 0), (64, 384, 256, 3, bf, bf, False, 0),
+    (64, 256, 256, 3, bf, bf, True, 0),
+    (32, 256, 256, 3, bf, bf, False, 0), (32, 256, 256, 3, bf, bf, True, 0), (32, 512, 512, 3, bf, bf, False, 0),
+    (32, 512, 512, 3, bf, bf, True, 0), (32, 768, 512, 3, bf, bf, False, 0), (32, 512, 256, 3, bf, bf, False, 1),
+    (64, 256, 128, 3, bf, bf, False, 1), (128, 128, 64, 3, bf, bf, False, 1),
 )
 
 
@@ -49,7 +50,7 @@ def main():
         x = torch.randn(B * H * H, C, device="cuda").to(adt)
         w = (torch.randn(N, k * k * C, device="cuda") / (k * k * C) ** 0.5).to(bf)
         out = torch.empty(B * OH * OH, N, device="cuda", dtype=odt)
-        r = torch.randn(B * OH * OH, N, device="cuda") if res else None
+        r = torch.randn(B * OH * OH, N, device="cuda").to(bf) if res else None
         ss = torch.randn(B, 2 * N, device="cuda")
         kw = dict(B=B, H=H, W=H, C_=C, N=N, KH=k, KW=k, pad=k // 2, ups=ups)
         if k == 3 and not res and not ups:
@@ -68,7 +69,7 @@ def main():
                 times[v].append(timeit(f, reps))
         lib.uwir_conv_variant(0)
         fl = 2.0 * B * OH * OH * N * k * k * C
-        by = x.numel() * x.element_size() + out.numel() * out.element_size() + (r.numel() * 4 if res else 0)
+        by = x.numel() * x.element_size() + out.numel() * out.element_size() + (r.numel() * 2 if res else 0)
         txt = "  ".join(f"v{v}: " + "/".join(f"{t:.1f}" for t in times[v]) + f" us ({fl / min(times[v]) / 1e6:.0f} TF/s)" for v in variants)
         dif = max(float((outs[v] - outs[variants[0]]).abs().max()) for v in variants)
         print(f"{H:3d}^2 C{C:<3d}->N{N:<3d} k{k} a={str(adt)[6:]:8s} out={str(odt)[6:]:8s} res={int(res)} ups={ups}: {txt}  "

@@ -17,7 +17,6 @@ struct GemmP {
     uwir_gemm_args a;
     int M, K, tiles_n, nblocks;  // nblocks = output tiles; the grid holds nblocks * splitk blocks
     int splitk;                  // > 1: K is cut into `splitk` slices, one block each (few-tile launches)
-    int dbg;                     // EXPERIMENT: ablation bits
 };
 
 // ---- deterministic split-K.  A launch with fewer output tiles than CUs (DA-CLIP: 800 token rows -> 42 tiles on 256
@@ -874,21 +873,21 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
         store_a(c0);
         store_w();
         __syncthreads();
-        if (!(p.dbg & 1)) load_w(1 * HC_TG * C + c0);
-        if (!(p.dbg & 4)) compute(std::integral_constant<int, 0>{});
+        load_w(1 * HC_TG * C + c0);
+        compute(std::integral_constant<int, 0>{});
         // ---- filter row 1
         __syncthreads();
         store_w();
         __syncthreads();
-        if (!(p.dbg & 1)) load_w(2 * HC_TG * C + c0);
-        if (chunk + 1 < nchunks && !(p.dbg & 2)) load_a(c0 + HC_BK);   // two compute stages ahead of its use
-        if (!(p.dbg & 4)) compute(std::integral_constant<int, 1>{});
+        load_w(2 * HC_TG * C + c0);
+        if (chunk + 1 < nchunks) load_a(c0 + HC_BK);   // two compute stages ahead of its use
+        compute(std::integral_constant<int, 1>{});
         // ---- filter row 2
         __syncthreads();
         store_w();
         __syncthreads();
-        if (chunk + 1 < nchunks && !(p.dbg & 1)) load_w(c0 + HC_BK);
-        if (!(p.dbg & 4)) compute(std::integral_constant<int, 2>{});
+        if (chunk + 1 < nchunks) load_w(c0 + HC_BK);
+        compute(std::integral_constant<int, 2>{});
     }
 
     int mrow[TM], mcnt[TM];
@@ -901,6 +900,183 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(GemmP p) {
     gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0 + wn0, fr, fq);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same halo-tile convolution for bf16 activations with no prologue affine (every 3x3 conv of the IR-SDE UNet once its
+// activation stream is bf16), with BOTH operands streamed global -> LDS by LDS-DMA.  The register-staged kernel above
+// holds the next stage's operands in VGPRs across a __syncthreads pair (whose vmcnt(0) ends every prefetch at the next
+// barrier): compiled without its MFMAs it still took 70 % of its time (32 x 32 maps, C = 512: 39 of 55 us), the load ->
+// LDS store -> barrier chain of each filter row being exposed by the 2 resident blocks per CU of the deep levels.  Here
+//   * weights: a ring of NS stages (one filter row x 32 channels x 64 output channels = 12 KiB, 3 DMA instructions per
+//     thread) filled NS - 1 stages ahead;
+//   * activations: the chunk's (TH + 2) x 18 halo tile (64 B per pixel), double buffered, filled one chunk (3 stages) ahead;
+//     padding pixels load a clamped address and are zeroed in LDS by the lane that owns them once its DMA has landed;
+//   * ONE raw s_barrier per stage, behind a COUNTED s_waitcnt vmcnt (DMA completes in issue order; the counts below are
+//     the instructions issued after the stage that is about to be read);
+// LDS image: 64-byte rows, piece p of row r at position p ^ hc_swz(r), image rows 20 LDS rows apart (row + 20 k flips
+// bit 1 of the swizzle for odd k: two read pointers per tap).  Block = 4 waves, TH x 16 pixels x 64 channels.
+// ------------------------------------------------------------------------------------------
+#define CD_PWL 20
+__device__ __forceinline__ void cd_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void cd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TH, int NS>
+__global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
+    constexpr int BN = 64, TM = TH / 4, TN = 4;
+    constexpr int A_ROWS = ((TH + 2) * CD_PWL + 63) / 64 * 64;   // LDS rows of one activation buffer: whole rounds of 4 x 16
+    constexpr int A_IT = A_ROWS / 64, W_IT = 3;                  // DMA instructions per thread: per chunk / per stage
+    constexpr int A_BYTES = A_ROWS * 64, W_BYTES = 3 * BN * 64;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * A_BYTES + NS * W_BYTES];
+
+    const uwir_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        int nwg = p.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int OH = g.OH, OW = g.OW, C = g.C, K = p.K;
+    const int tiles_x = (OW + HC_TW - 1) / HC_TW, tiles_y = (OH + TH - 1) / TH;
+    const int n0 = (bid % p.tiles_n) * BN;
+    int mt = bid / p.tiles_n;
+    const int tx = mt % tiles_x; mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int b = mt / tiles_y;
+    const int y0 = ty * TH, x0 = tx * HC_TW;
+
+    // ---- DMA descriptors.  Instruction `it` of wave w fills LDS rows (it * 4 + w) * 16 .. + 15, lane = row * 4 + position
+    unsigned a_off[A_IT], a_pad = 0;   // bit it of a_pad: this lane's piece is padding of a pixel that is read
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int rho = (it * 4 + wave) * 16 + (lane >> 2);
+        const int py = rho / CD_PWL, px = rho % CD_PWL;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        const bool used = py < TH + 2 && px < HC_PW;
+        const bool in = iy >= 0 && iy < OH && ix >= 0 && ix < OW;
+        if (used && !in) a_pad |= 1u << it;
+        const int cy = used && in ? iy : 0, cx = used && in ? ix : 0;
+        a_off[it] = ((unsigned)((b * g.H + (cy >> g.ups)) * g.W + (cx >> g.ups)) * (unsigned)g.lda +
+                     (unsigned)(((lane & 3) ^ hc_swz(rho)) * 8)) * 2u;
+    }
+    unsigned w_off[W_IT];
+    {
+        const int r = wave * 16 + (lane >> 2);                     // LDS row of the 64-channel block: holds channel pi(r)
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j)
+            w_off[j] = ((unsigned)(n0 + chan_perm(r)) * (unsigned)K + (unsigned)(j * C + ((lane & 3) ^ hc_swz(r)) * 8)) * 2u;
+    }
+    const char* a_base = (const char*)g.A;
+    const char* w_base = (const char*)g.Wt;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const unsigned lds_w = lds0 + 2 * A_BYTES;
+    const int nchunks = C / HC_BK, S = 3 * nchunks;
+    auto issue_w = [&](int s) {                                    // stage s = chunk s / 3, filter row s % 3
+        const int c = s / 3, gr = s - 3 * c;
+        const char* wb = w_base + (size_t)(gr * 3 * C + c * HC_BK) * 2;
+        const unsigned dst = lds_w + (s % NS) * W_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) cd_dma16(wb, w_off[j], dst + j * 4096);
+    };
+    auto issue_a = [&](int c) {
+        const char* ab = a_base + (size_t)c * (HC_BK * 2);
+        const unsigned dst = lds0 + (c & 1) * A_BYTES + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) cd_dma16(ab, a_off[it], dst + it * 4096);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wr0 = wave * TM;
+    int a_rd[HC_TG][2];                                            // byte offsets into an activation buffer, by (tap, parity of i + ky)
+#pragma unroll
+    for (int t = 0; t < HC_TG; ++t) {
+        const int r = wr0 * CD_PWL + fr + t;
+        a_rd[t][0] = r * 64 + (fq ^ hc_swz(r)) * 16;
+        a_rd[t][1] = r * 64 + (fq ^ hc_swz(r) ^ 2) * 16;
+    }
+    const int w_rd = fr * 64 + (fq ^ hc_swz(fr)) * 16;
+
+    auto compute = [&](auto grp_tag, const char* sa, const char* sw) {
+        constexpr int grp = decltype(grp_tag)::value;
+#pragma unroll
+        for (int tapl = 0; tapl < HC_TG; ++tapl) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + grp) & 1] + (i + grp) * (CD_PWL * 64));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sw + w_rd + (tapl * BN + j * 16) * 64);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // one stage: wait (counted) for this stage's operands, barrier, refill the ring slot / buffer that the barrier freed,
+    // compute.  WN = DMA instructions that may still be in flight when stage s is read (issued after it), steady state
+    // and last chunk.
+    auto stage = [&](auto grp_tag, int c, bool last) {
+        constexpr int grp = decltype(grp_tag)::value;
+        constexpr int steady = grp == 0 ? W_IT * (NS - 2) : (grp == 1 || NS >= 3) ? W_IT * (NS - 2) + A_IT : 0;
+        constexpr int tail = grp == 0 ? W_IT * (NS - 2 < 2 ? NS - 2 : 2) : grp == 1 ? W_IT * (NS - 2 < 1 ? NS - 2 : 1) : 0;
+        const int s = 3 * c + grp;
+        if (last) cd_wait_vm<tail>(); else cd_wait_vm<steady>();
+        if (grp == 0 && a_pad) {                                   // zero the padding pieces this lane's DMA just wrote
+            char* mine = smem + (c & 1) * A_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                if ((a_pad >> it) & 1) *reinterpret_cast<float4*>(mine + it * 4096) = make_float4(0.f, 0.f, 0.f, 0.f);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + NS - 1 < S) issue_w(s + NS - 1);
+        if (grp == 0 && !last) issue_a(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(grp_tag, smem + (c & 1) * A_BYTES, smem + 2 * A_BYTES + (s % NS) * W_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    issue_a(0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < S) issue_w(s);
+    for (int c = 0; c < nchunks; ++c) {
+        const bool last = c + 1 == nchunks;
+        stage(std::integral_constant<int, 0>{}, c, last);
+        stage(std::integral_constant<int, 1>{}, c, last);
+        stage(std::integral_constant<int, 2>{}, c, last);
+    }
+
+    int mrow[TM], mcnt[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oy = y0 + wr0 + i;
+        mrow[i] = (b * OH + oy) * OW + x0;
+        mcnt[i] = oy < OH ? OW - x0 : 0;
+    }
+    gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0, fr, fq);
+}
+
+static int g_conv_dma = 1;    // tools/: uwir_conv_variant bits 3-5: 0 default, 1 DMA conv off, 2.. forced tile / ring shapes
+static bool conv_dma_eligible(const uwir_gemm_args& g, int K) {
+    // 32-bit byte offsets from the tensor bases; weights in whole 64-channel blocks; no prologue affine.  C = 64 (two
+    // chunks: the pipeline never fills) stays on the register-staged kernel and its four blocks per CU: 256^2 C64->64
+    // 62.6 us there, 70.8 - 77 us here.
+    return g.a_dtype == UWIR_BF16 && !g.a_scale && g.N % 64 == 0 && (g.C > 64 || g_conv_dma >= 2) && ((uintptr_t)g.A & 15) == 0 &&
+           (unsigned long long)g.B * g.H * g.W * g.lda * 2ull < 0xffffffffull && (unsigned long long)g.N * K * 2ull < 0xffffffffull;
+}
+
 static bool halo_eligible(const uwir_gemm_args& g) {
     return g.compute == UWIR_BF16 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.C % HC_BK == 0 &&
            g.OH == (g.H << g.ups) && g.OW == (g.W << g.ups) && g.lda % 8 == 0;
@@ -910,11 +1086,9 @@ static int g_gemm_wide = 1;   // tools/: uwir_conv_variant(2) keeps the large-K 
 static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
                               // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
 void uwir_fft_set_radix4(int on);   // fft.hip
-static int g_halo_dbg = 0, g_halo_th4 = 0;
 extern "C" void uwir_conv_variant(int v) {
     g_halo_th16 = v & 1;
-    g_halo_th4 = (v >> 3) & 1;
-    g_halo_dbg = (v >> 4) & 7;
+    g_conv_dma = ((v >> 3) & 7) == 0 ? 1 : ((v >> 3) & 7) == 1 ? 0 : ((v >> 3) & 7);
     g_gemm_wide = (v & 2) ? 0 : 1;
     uwir_fft_set_radix4((v & 4) ? 0 : 1);
 }
@@ -922,28 +1096,45 @@ extern "C" void uwir_conv_variant(int v) {
 template <typename TA>
 static int launch_halo(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
-    p.dbg = g_halo_dbg;
     // optional 16-row tiles (256 pixels per block: TM doubles, i.e. half the weight re-staging and barriers per pixel and
     // 0.5 instead of 0.75 LDS fragment reads per MFMA at N = 64): measured no faster, off by default
     const long long mt16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW);
     const bool th16 = g_halo_th16 && p.a.N <= 64 && mt16 >= 1024;
-    int th = th16 ? 16 : 8;
-    long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
+    const int th = th16 ? 16 : 8;
+    const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
     int bn = p.a.N <= 64 ? 64 : 128;
     if (bn == 128 && mtiles * ceil_div(p.a.N, 128) < 512) bn = 64;
-    if (g_halo_th4 && bn == 64 && mtiles * ceil_div(p.a.N, 64) <= 1024) {
-        th = 4;
-        mtiles = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW);
-    }
     p.tiles_n = ceil_div(p.a.N, bn);
     const long long nb = mtiles * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
-    if (th == 4) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 4>), dim3(p.nblocks), dim3(256), 0, stream, p);
-    else if (bn == 64 && th16) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 16>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    if (bn == 64 && th16) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 16>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 64, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<TA, 128, 8>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm(halo)");
+    return UWIR_OK;
+}
+
+static int launch_conv_dma(const GemmP& p0, hipStream_t stream) {
+    GemmP p = p0;
+    // Tile / ring shape (tools/bench_conv.py, B = 8): 16-row tiles (half the weight traffic and LDS fragment reads per
+    // MFMA, ring of 2) win wherever they still give two blocks per CU -- 64^2 C384->256 66.7 (register-staged) / 60.2
+    // (8 rows, ring 3) / 54.5 us; 128^2 C192->128 75.4 / 67.8 / 63.3; nearest-2x 32^2 -> 64^2 C512->256 77 / 70 / 60.6 --
+    // below that 8-row tiles with a ring of 3: 32^2 C512->512 50.3 / 41.7 / 44.9, 32^2 C256->256 22.4 / 17.4 / 27.
+    int shape = g_conv_dma;                       // forced by tools/: 2 = 8 rows, ring 4; 3 = 8 rows, ring 3; 4 = 16 rows, ring 2
+    if (shape < 2) {
+        const long long nb16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW) * (p.a.N / 64);
+        shape = nb16 >= 512 ? 4 : 3;
+    }
+    const int th = shape == 4 ? 16 : 8;
+    p.tiles_n = p.a.N / 64;
+    const long long nb = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW) * p.tiles_n;
+    if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
+    p.nblocks = (int)nb;
+    if (shape == 2) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 4>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else if (shape == 3) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 3>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_dma_kernel<16, 2>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    UWIR_LAUNCH_CHECK("conv_gemm(dma)");
     return UWIR_OK;
 }
 
@@ -1075,9 +1266,9 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.tiles_n = 0;
     p.nblocks = 0;
     p.splitk = 1;
-    p.dbg = 0;
     hipStream_t s = (hipStream_t)stream;
     if (halo_eligible(g)) {
+        if (g_conv_dma && conv_dma_eligible(g, p.K)) return launch_conv_dma(p, s);
         if (g.a_dtype == UWIR_F32) return launch_halo<float>(p, s);
         if (g.a_dtype == UWIR_BF16) return launch_halo<bf16_t>(p, s);
     }
