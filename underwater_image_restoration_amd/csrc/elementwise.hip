@@ -353,34 +353,56 @@ extern "C" int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, co
 // per-(b,c) affine a*x + s for the consumer GEMM's normalise-on-load.  Statistics: the per-channel
 // shifted partial sums of ln_partial_kernel, merged per group in fp64 (parallel-variance formula).
 // ------------------------------------------------------------------------------------------
+// One wave per (b, group): lane = (channel j of the group, chunk lane kk); the chunk sums of a channel are spread over
+// its 64 / cg lanes and combined by xor shuffles (a single thread per group walking cg x nchunks fp64 records took 23 us
+// at B = 8, C = 512, n = 1024 -- longer than the statistics pass itself).
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ x, int ldx, int n, int C, int groups,
                                                           const double* __restrict__ part, int nchunks, float eps,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ a_out,
                                                           float* __restrict__ s_out, int B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * groups) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= B * groups) return;                                   // wave-uniform
     const int b = i / groups, g = i % groups, cg = C / groups;
+    // cgp = lanes along the channel axis (power of two >= cg, at most 64); channels beyond 64 per group loop
+    int cgp = 1;
+    while (cgp < cg && cgp < 64) cgp <<= 1;
+    const int kl = 64 / cgp, jl = lane % cgp, kk = lane / cgp;
     double sum_mean = 0, sum_m2 = 0, sum_mean2 = 0;
-    for (int j = 0; j < cg; ++j) {
-        const int c = g * cg + j;
+    for (int j0 = 0; j0 < cg; j0 += cgp) {
+        const int j = j0 + jl;
+        const bool ok = j < cg;
+        const int c = g * cg + (ok ? j : 0);
         double s = 0, ss = 0;
-        for (int k = 0; k < nchunks; ++k) {
-            const double* p = part + (((size_t)b * nchunks + k) * C + c) * 2;
-            s += p[0];
-            ss += p[1];
+        if (ok)
+            for (int k = kk; k < nchunks; k += kl) {
+                const double* p = part + (((size_t)b * nchunks + k) * C + c) * 2;
+                s += p[0];
+                ss += p[1];
+            }
+        for (int off = cgp; off < 64; off <<= 1) {                  // over the chunk lanes of this channel
+            s += __shfl_xor(s, off);
+            ss += __shfl_xor(ss, off);
         }
-        const double md = s / n;
-        const double mean = (double)x[(size_t)b * n * ldx + c] + md;
-        sum_mean += mean;
-        sum_mean2 += mean * mean;
-        sum_m2 += ss - s * md;
+        if (ok && kk == 0) {
+            const double md = s / n;
+            const double mean = (double)x[(size_t)b * n * ldx + c] + md;
+            sum_mean += mean;
+            sum_mean2 += mean * mean;
+            sum_m2 += ss - s * md;
+        }
+    }
+    for (int off = 1; off < 64; off <<= 1) {                        // over the channels (lanes with kk != 0 hold zeros)
+        sum_mean += __shfl_xor(sum_mean, off);
+        sum_mean2 += __shfl_xor(sum_mean2, off);
+        sum_m2 += __shfl_xor(sum_m2, off);
     }
     const double gmean = sum_mean / cg;
     double var = (sum_m2 + (double)n * (sum_mean2 - cg * gmean * gmean)) / ((double)n * cg);
     if (var < 0) var = 0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int j = 0; j < cg; ++j) {
+    for (int j = lane; j < cg; j += 64) {
         const int c = g * cg + j;
         const double a = rstd * (double)gamma[c];
         a_out[(size_t)b * C + c] = (float)a;
@@ -402,7 +424,7 @@ extern "C" int uwir_groupnorm_affine(const float* x, int ldx, int B, int n, int 
     hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
                        nchunks);
     UWIR_LAUNCH_CHECK("gn_partial");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * groups, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * groups, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
                        C, groups, (const double*)workspace, nchunks, eps, gamma, beta, a_out, s_out, B);
     UWIR_LAUNCH_CHECK("gn_finalize");
     return UWIR_OK;

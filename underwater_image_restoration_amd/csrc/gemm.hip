@@ -1172,7 +1172,8 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     long long nb = (long long)ceil_div(p.M, 128) * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
-    if (glds_eligible(p.a, p.K) && p.nblocks < 256) {
+    // (one block per CU and a long K: M8192 N512 K2048 42 -> 33 us double-buffered; shorter K gains nothing)
+    if (glds_eligible(p.a, p.K) && (p.nblocks < 256 || (p.nblocks == 256 && p.K >= 1536))) {
         // fewer tiles than CUs: per-tile latency is what matters.  Double-buffered staging (57 -> 44 us at M800 N768
         // K3072) and, when the caller lent a workspace, split-K (see splitk_dump)
         p.splitk = splitk_factor(p.M, p.a.N, p.K, p.a.workspace, p.a.workspace_bytes);

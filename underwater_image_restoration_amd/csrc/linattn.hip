@@ -156,25 +156,27 @@ __global__ void __launch_bounds__(256) la_kv_fused_kernel(const TX* __restrict__
     for (int r = 0; r < 16; ++r) o[2 * D + ((r & 3) + 8 * (r >> 2) + 4 * lh) * D + lq] = acc[r];
 }
 
-// chunks -> ctx^T[b][head][e][d] * (D^-0.5 / n), bf16.  One block per (b, head); thread = (d, chunk lane cl, group of
-// 4 e): the chunk loop is split four ways (a single thread walking 128 chunk records is a chain of L2 round trips),
-// the four partial sums are combined through LDS in a fixed order (deterministic).
+// chunks -> ctx^T[b][head][e][d] * (D^-0.5 / n), bf16.  One block per (b, head, group of 4 e); thread = (d, chunk lane cl):
+// 32 chunk lanes, so a thread walks nchunks / 32 records (one block per (b, head) with 4 chunk lanes was a chain of
+// 2 x 32 dependent L2 round trips: 16 us per call, six calls per UNet step); the lanes' partial sums are combined through
+// LDS in a fixed order (deterministic).
+#define LF_FIN_CL 32
 __global__ void __launch_bounds__(1024) la_fin_fused_kernel(const float* __restrict__ part, int nchunks, float inv_n_scale,
                                                             bf16_t* __restrict__ ctxT) {
-    constexpr int D = LF_D, REC = 2 * D + D * D, CL = 4;
+    constexpr int D = LF_D, REC = 2 * D + D * D, CL = LF_FIN_CL;
     __shared__ float s_m[CL][D];
     __shared__ float s_s[CL][D];
-    __shared__ float s_a[CL][D][D + 1];
-    const int bh = blockIdx.x, d = threadIdx.x & 31, cl = (threadIdx.x >> 5) & 3, eg = threadIdx.x >> 7;
+    __shared__ float s_a[CL][4][D];
+    const int bh = blockIdx.x >> 3, eg = blockIdx.x & 7, d = threadIdx.x & 31, cl = threadIdx.x >> 5;
     const float* p0 = part + (size_t)bh * nchunks * REC;
     float m = -INFINITY;
-#pragma unroll 8
     for (int c = cl; c < nchunks; c += CL) m = fmaxf(m, p0[(size_t)c * REC + d]);
-    if (eg == 0) s_m[cl][d] = m;
+    s_m[cl][d] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(s_m[0][d], s_m[1][d]), fmaxf(s_m[2][d], s_m[3][d]));
+    m = s_m[0][d];
+#pragma unroll
+    for (int k = 1; k < CL; ++k) m = fmaxf(m, s_m[k][d]);
     float a[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
-#pragma unroll 4
     for (int c = cl; c < nchunks; c += CL) {
         const float* p = p0 + (size_t)c * REC;
         const float w = __builtin_amdgcn_exp2f(p[d] - m);
@@ -182,18 +184,15 @@ __global__ void __launch_bounds__(1024) la_fin_fused_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = fmaf(w, p[2 * D + (eg * 4 + i) * D + d], a[i]);
     }
-    if (eg == 0) s_s[cl][d] = sum;
+    s_s[cl][d] = sum;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_a[cl][eg * 4 + i][d] = a[i];
+    for (int i = 0; i < 4; ++i) s_a[cl][i][d] = a[i];
     __syncthreads();
-    if (cl == 0) {
-        const float st = (s_s[0][d] + s_s[1][d]) + (s_s[2][d] + s_s[3][d]);
+    if (cl < 4) {                                                  // thread (d, i = cl): fixed-order sums over the chunk lanes
+        float st = 0.f, at = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = eg * 4 + i;
-            const float at = (s_a[0][e][d] + s_a[1][e][d]) + (s_a[2][e][d] + s_a[3][e][d]);
-            ctxT[(size_t)bh * D * D + e * D + d] = (bf16_t)(at / st * inv_n_scale);
-        }
+        for (int k = 0; k < CL; ++k) { st += s_s[k][d]; at += s_a[k][cl][d]; }
+        ctxT[(size_t)bh * D * D + (eg * 4 + cl) * D + d] = (bf16_t)(at / st * inv_n_scale);
     }
 }
 
@@ -421,7 +420,7 @@ extern "C" int uwir_linattn_block(const void* x, int io_dtype, int ldx, int B, i
     hipLaunchKernelGGL((la_kv_fused_kernel<DIM_, TX_>), dim3(nchunks, B), dim3(256), 0, s, (const TX_*)x, ldx, n, rpc,     \
                        nchunks, g_pre, eps, wq, part);                                                                     \
     UWIR_LAUNCH_CHECK("linattn_block(kv)");                                                                                \
-    hipLaunchKernelGGL(la_fin_fused_kernel, dim3(B * LF_HEADS), dim3(1024), 0, s, part, nchunks, inv_n_scale, ctxT);          \
+    hipLaunchKernelGGL(la_fin_fused_kernel, dim3(B * LF_HEADS * 8), dim3(1024), 0, s, part, nchunks, inv_n_scale, ctxT);          \
     UWIR_LAUNCH_CHECK("linattn_block(fin)");                                                                               \
     hipLaunchKernelGGL((la_apply_fused_kernel<DIM_, TX_>), dim3(ceil_div(n, 128 * rgw), B), dim3(256), 0, s,               \
                        (const TX_*)x, ldx, n, g_pre, eps, wq, ctxT, wo, b_out, g_out, (TX_*)out, ldo, rgw);                \
