@@ -177,7 +177,7 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * <= n 2^90 <= 2^107 for n <= 2^17; O <= l max|v|, finite for |v| < 2^20), the (mathematically cancelling) softmax
  * shift is dropped and no running max / rescale is computed; blocks with a larger bound run the online-max loop.
  * With >= uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) bytes, 256-byte aligned, long bf16 sequences with
- * hd 16 or 32 (n >= 2048, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
+ * hd 16 or 32 (n >= 1024, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
  * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier.  The
  * results are the same function of the inputs to bf16 rounding; shapes outside that range return the small size. */
 /* Measurement hook with no counterpart in the reference: arms two hipEvent_t for the NEXT uwir_flash_attn call of the

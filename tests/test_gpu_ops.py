@@ -718,7 +718,7 @@ def _attn_ref_cuda(q, k, vs, b, n, heads, hd):
 
 
 @pytest.mark.parametrize("cfg", [(1, 4096, 16, 16, 1), (1, 2100, 32, 16, 2), (1, 2049, 32, 32, 1), (2, 2500, 13, 32, 2),
-                                 (1, 2048, 32, 16, 1)])
+                                 (1, 2048, 32, 16, 1), (2, 1030, 64, 32, 1), (8, 1024, 8, 32, 1)])
 def test_flash_attn_packed_stream(ops, cfg):
     """Long bf16 sequences with hd 16 / 32 take the packed-stream kernels (pre-packed K / V^T fragments, no LDS):
     parity with the fp64 softmax attention, agreement with the LDS-staged kernels, ragged n (keys padded to 32,
