@@ -125,12 +125,19 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
 #pragma unroll
         for (int j = 0; j < TN; ++j) v[j] += t[j];
     }
-    if (g.act != UWIR_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[j][e] = act_apply(v[j][e], g.act);
+    // one block-uniform dispatch per call, not one per element (act_apply's switch inside the 16-element loop compiled to
+    // a chain of scalar branches around every element: it tripled the epilogue of the resident-weight conv kernel)
+#define UWIR_EPI_ACT(EXPR)                                                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float x = v[j][e]; v[j][e] = (EXPR); }
+    switch (g.act) {
+        case UWIR_ACT_RELU: UWIR_EPI_ACT(x > 0.f ? x : 0.f) break;
+        case UWIR_ACT_GELU: UWIR_EPI_ACT(act_apply(x, UWIR_ACT_GELU)) break;
+        case UWIR_ACT_SIGMOID: UWIR_EPI_ACT(sigmoid_fast(x)) break;
+        case UWIR_ACT_SILU: UWIR_EPI_ACT(x * sigmoid_fast(x)) break;
+        default: break;
     }
+#undef UWIR_EPI_ACT
     if (g.col_scale) {
         f32x4 t[TN];
 #pragma unroll
@@ -1068,12 +1075,270 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
     gemm_epilogue<TM, TN>(g, acc, mrow, mcnt, n0, fr, fq);
 }
 
+// ------------------------------------------------------------------------------------------
+// Short-K form (C <= 64: the 64-channel levels of the IR-SDE UNet, K = 576): six filter-row stages per tile never fill a
+// pipeline, and a block's prologue (first operands' latency) and epilogue (residual loads, stores) outweigh its 1.1 us of
+// MFMAs -- 515 TF/s on the register-staged kernel at 4 blocks per CU, no better on the ring above.  Here the block is
+// PERSISTENT (one per CU) and keeps the whole 64-channel weight slice in LDS (72 KiB, loaded once); only halo tiles
+// stream.  Its 8 waves are two groups of 4 that walk separate lists of 8 x 16 pixel tiles with their own double-buffered
+// halo tiles; one block-wide s_barrier per 32-channel chunk.  Group 0 runs compute -> epilogue inside a barrier interval,
+// group 1 runs (previous tile's epilogue) -> compute, so each SIMD always has one wave issuing MFMAs while the other
+// loads residuals / stores.  Operand waits: the next chunk's DMA is issued right after the barrier and awaited with
+// vmcnt(0) at the END of the chunk's MFMAs, BEFORE the epilogue issues its stores (loads and stores share vmcnt and
+// complete out of order between them: a counted wait with stores in flight proves nothing).
+// ------------------------------------------------------------------------------------------
+template <int NCH>   // 32-channel chunks per tile: C = 32 * NCH
+__global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
+    constexpr int BN = 64, TH = 8, TM = 2, TN = 4, NB = 3;         // NB halo buffers per group: DMA runs two chunks ahead
+    constexpr int A_PIECES = ((TH + 2) * CD_PWL + 15) / 16;        // 13 wave-instructions of 16 LDS rows (the last is partial)
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int W_BYTES = NCH * 9 * BN * 64;                     // [chunk][tap][64 rows][64 B]
+    constexpr int W_IT = W_BYTES / (512 * 16);
+    static_assert(W_BYTES % (512 * 16) == 0, "weight image must be whole DMA rounds of the block");
+    static_assert(W_BYTES + 2 * NB * A_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[W_BYTES + 2 * NB * A_BYTES];
+
+    const uwir_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    const int OH = g.OH, OW = g.OW, C = g.C, K = p.K;
+    const int tiles_x = (OW + HC_TW - 1) / HC_TW, tiles_y = (OH + TH - 1) / TH;
+    const int mtiles = g.B * tiles_y * tiles_x;
+    const int nt = blockIdx.x % p.tiles_n, mblk = blockIdx.x / p.tiles_n, nmblk = gridDim.x / p.tiles_n;
+    const int n0 = nt * BN;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const unsigned lds_a = lds0 + W_BYTES + grp * NB * A_BYTES;
+    char* sa_base = smem + W_BYTES + grp * NB * A_BYTES;
+
+    // ---- the weight slice: LDS row r of (chunk c, tap t) holds channel n0 + pi(r), pieces swizzled by the row
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int slot = it * 8 + wave8;                           // 1 KiB = 16 rows
+        const int img = slot >> 2, r = (slot & 3) * 16 + (lane >> 2);   // img = c * 9 + t
+        const int c = img / 9, t = img - 9 * c;
+        const unsigned off = ((unsigned)(n0 + chan_perm(r)) * (unsigned)K + (unsigned)(t * C + c * HC_BK + ((lane & 3) ^ hc_swz(r)) * 8)) * 2u;
+        cd_dma16(g.Wt, off, lds0 + slot * 1024);
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wr0 = wave * TM;
+    int a_rd[HC_TG][2];
+#pragma unroll
+    for (int t = 0; t < HC_TG; ++t) {
+        const int r = wr0 * CD_PWL + fr + t;
+        a_rd[t][0] = r * 64 + (fq ^ hc_swz(r)) * 16;
+        a_rd[t][1] = r * 64 + (fq ^ hc_swz(r) ^ 2) * 16;
+    }
+    const int w_rd = fr * 64 + (fq ^ hc_swz(fr)) * 16;
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute_chunk = [&](const char* sa, const char* sw) {      // 3 filter rows x 3 taps of one 32-channel chunk
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int tapl = 0; tapl < HC_TG; ++tapl) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + ky) & 1] + (i + ky) * (CD_PWL * 64));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const bf16x8*>(sw + w_rd + ((ky * 3 + tapl) * BN + j * 16) * 64);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // this group's tile list: (mblk * 2 + grp) + k * 2 * nmblk, k = 0, 1, ..; chunk sequence number q = k * NCH + c
+    auto tile_of = [&](int k) {
+        const long long t = (long long)(mblk * 2 + grp) + (long long)k * 2 * nmblk;
+        return t < mtiles ? (int)t : -1;
+    };
+    struct Tile { int b, y0, x0; };
+    auto coords = [&](int t) {
+        Tile r;
+        r.x0 = (t % tiles_x) * HC_TW;
+        t /= tiles_x;
+        r.y0 = (t % tiles_y) * TH;
+        r.b = t / tiles_y;
+        return r;
+    };
+    // wave w issues pieces w, w + 4, ..: wave 0 one more than the others (13 pieces)
+    const int my_pieces = (A_PIECES - wave + 3) / 4;
+    // DMA of chunk q (tile list position q / NCH) into buffer q % NB; returns the mask of this lane's padding pieces
+    auto issue_a = [&](int q) -> unsigned {
+        const int t = tile_of(q / NCH), c = q % NCH;
+        if (t < 0) return 0u;
+        const Tile tc = coords(t);
+        unsigned pad = 0;
+        const char* ab = (const char*)g.A + (size_t)c * (HC_BK * 2);
+        const unsigned dst = lds_a + (q % NB) * A_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int piece = it * 4 + wave;
+            if (piece < A_PIECES) {                                // wave-uniform
+                const int rho = piece * 16 + (lane >> 2);
+                const int py = rho / CD_PWL, px = rho % CD_PWL;
+                const int iy = tc.y0 + py - 1, ix = tc.x0 + px - 1;
+                const bool used = py < TH + 2 && px < HC_PW;
+                const bool in = iy >= 0 && iy < OH && ix >= 0 && ix < OW;
+                if (used && !in) pad |= 1u << it;
+                const int cy = used && in ? iy : 0, cx = used && in ? ix : 0;
+                const unsigned off = ((unsigned)((tc.b * g.H + (cy >> g.ups)) * g.W + (cx >> g.ups)) * (unsigned)g.lda +
+                                      (unsigned)(((lane & 3) ^ hc_swz(rho)) * 8)) * 2u;
+                cd_dma16(ab, off, dst + piece * 1024);
+            }
+        }
+        return pad;
+    };
+    auto zero_pad = [&](unsigned pad, int q) {                      // after the chunk's DMA has landed, before the barrier
+        if (pad) {
+            char* mine = sa_base + (q % NB) * A_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if ((pad >> it) & 1) *reinterpret_cast<float4*>(mine + it * 4096) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // chunk q + 1 has landed: at most the pieces of chunk q + 2 (the only younger LOADS) may be in flight.  Loads retire in
+    // order among themselves, so stores still in flight can only make this wait longer, never shorter.
+    auto wait_next = [&](bool two_ahead_issued) {
+        if (!two_ahead_issued) cd_wait_vm<0>();
+        else if (wave == 0) cd_wait_vm<4>();
+        else cd_wait_vm<3>();
+    };
+    // ---- epilogue with its operands PREFETCHED.  The shared gemm_epilogue loads per-sample scale, per-sample bias and the
+    // residual in turn, each behind a block-uniform branch: three dependent memory round trips per tile row, which the
+    // other kernels hide behind their many resident blocks and this one cannot (256^2, C 64 -> 64, B = 8: 41 us without an
+    // epilogue, 105 with the shared one, 58 with this one; the register-staged kernel takes 65).  Here everything a tile's
+    // epilogue reads is requested before the tile's last chunk of MFMAs, and the activation is dispatched once per tile.
+    // Supported (checked on the host): bias, batch_scale, batch_bias, activation, bf16 residual, plain bf16 / fp32 rows.
+    const int nq0 = n0 + fq * 16;                                  // this lane's 16 channels: nq0 + j * 4 .. + 3
+    f32x4 e_bias[TN], e_bs[TN], e_bb[TN];
+    uint2 e_res[TM][TN];
+    long long e_row[TM];                                           // output row of (tile row i, pixel fr), or -1
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        e_bias[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nq0 + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bld = g.batch_ld ? g.batch_ld : g.N;
+    const bool silu = g.act == UWIR_ACT_SILU;
+    const float* e_bsp = g.batch_scale;
+    const float* e_bbp = g.batch_bias;
+    const void* e_resp = g.res;
+    auto epi_prefetch = [&](int t) {
+        const Tile tc = coords(t);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (e_bsp) e_bs[j] = *reinterpret_cast<const f32x4*>(e_bsp + (size_t)tc.b * bld + nq0 + j * 4);
+            if (e_bbp) e_bb[j] = *reinterpret_cast<const f32x4*>(e_bbp + (size_t)tc.b * bld + nq0 + j * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int oy = tc.y0 + wr0 + i, ox = tc.x0 + fr;
+            const bool ok = oy < OH && ox < OW;
+            e_row[i] = ok ? ((long long)tc.b * OH + oy) * OW + ox : -1;
+            if (e_resp) {
+                const bf16_t* rp = (const bf16_t*)e_resp + (size_t)(ok ? e_row[i] : 0) * g.ldr + nq0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) e_res[i][j] = *reinterpret_cast<const uint2*>(rp + j * 4);
+            }
+        }
+    };
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f32x4 v[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                v[j] = acc[i][j] + e_bias[j];
+                if (e_bsp) v[j] *= e_bs[j];
+                if (e_bbp) v[j] += e_bb[j];
+                if (silu) {                                        // (block-uniform; the host admits NONE and SILU only)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * sigmoid_fast(v[j][e]);
+                }
+                if (e_resp) {
+                    const unsigned lo = e_res[i][j].x, hi = e_res[i][j].y;
+                    v[j][0] += __uint_as_float(lo << 16);
+                    v[j][1] += __uint_as_float(lo & 0xffff0000u);
+                    v[j][2] += __uint_as_float(hi << 16);
+                    v[j][3] += __uint_as_float(hi & 0xffff0000u);
+                }
+            }
+            if (e_row[i] < 0) continue;
+            if (g.out_dtype == UWIR_BF16) {
+                bf16_t* op = (bf16_t*)g.out + (size_t)e_row[i] * g.ldo + nq0;
+#pragma unroll
+                for (int jp = 0; jp < TN; jp += 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[jp][e]; o[4 + e] = (bf16_t)v[jp + 1][e]; }
+                    *reinterpret_cast<bf16x8*>(op + jp * 4) = o;
+                }
+            } else {
+                float* op = (float*)g.out + (size_t)e_row[i] * g.ldo + nq0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(op + j * 4) = v[j];
+            }
+        }
+    };
+
+    const int iters = (int)(((long long)mtiles + 2LL * nmblk - 1) / (2LL * nmblk));   // group 0's tile count (>= group 1's)
+    const int nq = iters * NCH;
+    unsigned pad1 = issue_a(0), pad2 = 0;                          // masks of the chunks in flight: q + 1 and q + 2
+    cd_wait_vm<0>();                                               // weights + chunk 0
+    zero_pad(pad1, 0);
+    pad1 = nq > 1 ? issue_a(1) : 0u;
+    int t_prev = -1;                                               // group 1: tile whose epilogue is still owed
+    zero_acc();
+    for (int q = 0; q < nq; ++q) {
+        const int c = q % NCH, t_cur = tile_of(q / NCH);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                              // chunk q is complete in LDS; buffer (q + 2) % NB is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1 && c == 0 && t_prev >= 0) {                   // the deferred epilogue of the previous tile
+            epilogue();
+            zero_acc();
+            t_prev = -1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == NCH - 1 && t_cur >= 0) epi_prefetch(t_cur);       // lands behind this chunk's MFMAs
+        const bool two = q + 2 < nq && tile_of((q + 2) / NCH) >= 0;
+        pad2 = two ? issue_a(q + 2) : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t_cur >= 0) compute_chunk(sa_base + (q % NB) * A_BYTES, smem + c * (9 * BN * 64));
+        __builtin_amdgcn_sched_barrier(0);
+        wait_next(two);
+        zero_pad(pad1, q + 1);
+        pad1 = pad2;
+        if (c == NCH - 1 && t_cur >= 0) {
+            if (grp == 0) {
+                epilogue();
+                zero_acc();
+            } else {
+                t_prev = t_cur;
+            }
+        }
+    }
+    if (grp == 1 && t_prev >= 0) epilogue();
+}
+
 static int g_conv_dma = 1;    // tools/: uwir_conv_variant bits 3-5: 0 default, 1 DMA conv off, 2.. forced tile / ring shapes
 static bool conv_dma_eligible(const uwir_gemm_args& g, int K) {
     // 32-bit byte offsets from the tensor bases; weights in whole 64-channel blocks; no prologue affine.  C = 64 (two
     // chunks: the pipeline never fills) stays on the register-staged kernel and its four blocks per CU: 256^2 C64->64
     // 62.6 us there, 70.8 - 77 us here.
-    return g.a_dtype == UWIR_BF16 && !g.a_scale && g.N % 64 == 0 && (g.C > 64 || g_conv_dma >= 2) && ((uintptr_t)g.A & 15) == 0 &&
+    return g.a_dtype == UWIR_BF16 && !g.a_scale && g.N % 64 == 0 && g.C >= 64 && ((uintptr_t)g.A & 15) == 0 &&
            (unsigned long long)g.B * g.H * g.W * g.lda * 2ull < 0xffffffffull && (unsigned long long)g.N * K * 2ull < 0xffffffffull;
 }
 
@@ -1117,11 +1382,28 @@ static int launch_halo(const GemmP& p0, hipStream_t stream) {
 
 static int launch_conv_dma(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
+    const uwir_gemm_args& ga = p.a;
+    const bool resw_epi = (ga.act == UWIR_ACT_NONE || ga.act == UWIR_ACT_SILU) && !ga.col_scale && !ga.blend_out && ga.store_mode == 0 && !ga.res_scale && ga.out &&
+                          (!ga.res || (ga.res_dtype == UWIR_BF16 && ga.ldr % 4 == 0)) &&
+                          ((uintptr_t)ga.out & 15) == 0 && ga.ldo % 8 == 0 &&
+                          (((uintptr_t)ga.bias | (uintptr_t)ga.batch_scale | (uintptr_t)ga.batch_bias) & 15) == 0;
+    if (p.a.C == 64 && g_conv_dma != 7 && resw_epi) {   // short K: persistent blocks with the weight slice resident in LDS
+        p.tiles_n = p.a.N / 64;
+        const long long mtiles = (long long)p.a.B * ceil_div(p.a.OH, 8) * ceil_div(p.a.OW, HC_TW);
+        long long nmblk = 256 / p.tiles_n;                     // one block per CU
+        if (nmblk < 1) nmblk = 1;
+        if (nmblk > (mtiles + 1) / 2) nmblk = (mtiles + 1) / 2;
+        p.nblocks = (int)(nmblk * p.tiles_n);
+        hipLaunchKernelGGL((conv3x3_resw_kernel<2>), dim3(p.nblocks), dim3(512), 0, stream, p);
+        UWIR_LAUNCH_CHECK("conv_gemm(resident weights)");
+        return UWIR_OK;
+    }
     // Tile / ring shape (tools/bench_conv.py, B = 8): 16-row tiles (half the weight traffic and LDS fragment reads per
     // MFMA, ring of 2) win wherever they still give two blocks per CU -- 64^2 C384->256 66.7 (register-staged) / 60.2
     // (8 rows, ring 3) / 54.5 us; 128^2 C192->128 75.4 / 67.8 / 63.3; nearest-2x 32^2 -> 64^2 C512->256 77 / 70 / 60.6 --
     // below that 8-row tiles with a ring of 3: 32^2 C512->512 50.3 / 41.7 / 44.9, 32^2 C256->256 22.4 / 17.4 / 27.
-    int shape = g_conv_dma;                       // forced by tools/: 2 = 8 rows, ring 4; 3 = 8 rows, ring 3; 4 = 16 rows, ring 2
+    int shape = g_conv_dma == 7 ? 1 : g_conv_dma; // forced by tools/: 2 = 8 rows, ring 4; 3 = 8 rows, ring 3; 4 = 16 rows, ring 2;
+                                                  // 7 = automatic, but C = 64 on the ring kernel instead of the resident-weight one
     if (shape < 2) {
         const long long nb16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW) * (p.a.N / 64);
         shape = nb16 >= 512 ? 4 : 3;
