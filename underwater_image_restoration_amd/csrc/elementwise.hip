@@ -940,6 +940,90 @@ extern "C" int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, i
     return UWIR_OK;
 }
 
+// The UNet's tail conv on bf16 rows (Cin = 32 or 64 -> Cout <= 4) on the matrix cores: the per-pixel FMA form above spends
+// 110 us on a map it could read in 15 (B = 8, 256 x 256, Cin 64).  v_mfma_f32_16x16x32_bf16 with the (<= 4 used of 16)
+// output channels as rows and 16 pixels of an image row as columns; the fp32 weights enter as hi + lo bf16 pairs (two
+// MFMAs per fragment: 16 mantissa bits, the last layer's weights are not rounded to bf16), staged once per block in LDS in
+// fragment order; the activation fragments are 16-byte global loads (pixel (y + ky - 1, x + kx - 1), 8 channels), zero
+// outside the image.  A wave walks 8 rows of a 16-pixel column strip; lanes 0-15 hold the pixel's channels 0-3.
+template <int NCH>
+__global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict__ x, int ldx, int H, int W,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                        float* __restrict__ out, int Ho, int Wo) {
+    constexpr int NF = 9 * NCH, Cin = 32 * NCH;
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[2 * NF * 64 * 8];   // [hi | lo][fragment = tap * NCH + chunk][lane][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    for (int i = tid; i < NF * 64; i += 256) {
+        const int f = i >> 6, l = i & 63, co = l & 15, kq = l >> 4, tap = f / NCH, c = f % NCH;
+        bf16x8 hi, lo;
+        float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (co < Cout) {
+            const float* wp = w + ((size_t)co * 9 + tap) * Cin + c * 32 + kq * 8;
+            const float4 w0 = load4(wp), w1 = load4(wp + 4);
+            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wv[j];
+            const bf16_t h = (bf16_t)v;
+            hi[j] = h;
+            lo[j] = (bf16_t)(v - (float)h);
+        }
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)i * 8]) = hi;
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)(NF * 64 + i) * 8]) = lo;
+    }
+    __syncthreads();
+    const int b = blockIdx.z, px = blockIdx.x * 16 + fr, ybase = blockIdx.y * 32 + wave * 8;
+    const bf16_t* xb = x + (size_t)b * H * W * ldx + fq * 8;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (bias && e < Cout) ? bias[e] : 0.f;
+    // rolling window over the input rows: fragments of rows y - 1, y, y + 1 are live, each new output row loads one row
+    auto load_row = [&](int iy, bf16x8 (&dst)[3 * NCH]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = px + kx - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const bf16_t* src = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ldx;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c * 32);
+                if (!ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+                }
+                dst[kx * NCH + c] = v;
+            }
+        }
+    };
+    bf16x8 rows[3][3 * NCH];
+    load_row(ybase - 1, rows[0]);
+    load_row(ybase, rows[1]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = ybase + r;
+        if (y < Ho) {                                               // wave-uniform
+            load_row(y + 1, rows[(r + 2) % 3]);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: hi and lo weights
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < 3 * NCH; ++t) {
+                    const int f = ky * 3 * NCH + t;                 // fragment = (ky * 3 + kx) * NCH + c
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)(f * 64 + lane) * 8]);
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)((NF + f) * 64 + lane) * 8]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rows[(r + ky) % 3][t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, rows[(r + ky) % 3][t], acc1, 0, 0, 0);
+                }
+            if (fq == 0 && px < Wo) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < Cout) out[(((size_t)b * Cout + e) * Ho + y) * Wo + px] = (acc0[e] + acc1[e]) + bv[e];
+            }
+        }
+    }
+}
+
 extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w,
                                  const float* bias, int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
     UWIR_CHECK(xv && w && out_nchw, "tail: null pointer");
@@ -948,6 +1032,18 @@ extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
     UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
                    ldx % 4 == 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W,
                "tail: bad shape (Cout<=%d, crop within the map)", HEAD_MAX_COUT);
+    if (x_dtype == UWIR_BF16 && (Cin == 32 || Cin == 64) && ldx % 8 == 0 && (((uintptr_t)xv | (uintptr_t)w) & 15) == 0 && B <= 65535 &&
+        ceil_div(Ho, 32) <= 65535) {
+        const dim3 grid(ceil_div(Wo, 16), ceil_div(Ho, 32), B);
+        if (Cin == 64)
+            hipLaunchKernelGGL(tail_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w, bias,
+                               Cout, out_nchw, Ho, Wo);
+        else
+            hipLaunchKernelGGL(tail_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w, bias,
+                               Cout, out_nchw, Ho, Wo);
+        UWIR_LAUNCH_CHECK("tail(mfma)");
+        return UWIR_OK;
+    }
     if (head_tiled_ok(B, Ho, Wo, Cin)) {
         if (x_dtype == UWIR_BF16)
             hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0,
