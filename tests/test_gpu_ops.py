@@ -945,3 +945,23 @@ def test_bf16_activation_stream_variants(ops):
     assert torch.equal(o16[:, :dim], o32.to(bf)) and float(o16[:, dim:].float().min()) == 5.0
     with pytest.raises(TypeError):
         ops.linattn_block(xq.cuda(), *args, o32, ws)
+
+
+def test_unet_stem_7x7_mfma(ops):
+    """The IR-SDE UNet's init conv (7x7, 8 zero-padded channels -> 64, fp32 rows in, bf16 rows out) has its own MFMA kernel:
+    ragged tiles (16-pixel strips, 32-row blocks), output into a column slice of a wider buffer, against fp64 on the
+    bf16-rounded operands; the generic implicit GEMM (fp32 output: not eligible) must agree."""
+    g = torch.Generator().manual_seed(91)
+    b, h, w, n = 2, 40, 50, 64
+    x = torch.randn(b, 8, h, w, generator=g)
+    x[:, 6:] = 0
+    wt = torch.randn(n, 8, 7, 7, generator=g) / math.sqrt(49 * 6)
+    wd = wt.permute(0, 2, 3, 1).reshape(n, -1).bfloat16().cuda().contiguous()
+    out = torch.full((b * h * w, 2 * n), 3.0, device="cuda", dtype=torch.bfloat16)
+    ops.conv_gemm(to_rows(x), wd, out[:, n:], B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
+    ref = F.conv2d(x.bfloat16().double(), wt.bfloat16().double(), padding=3)
+    assert rel(from_rows(out[:, n:].float(), b, h, w), ref) < 6e-3 and float(out[:, :n].float().min()) == 3.0
+    o32 = torch.empty(b * h * w, n, device="cuda")
+    ops.conv_gemm(to_rows(x), wd, o32, B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
+    assert rel(from_rows(o32, b, h, w), ref) < 1e-4
+    assert float((out[:, n:].float() - o32).abs().max()) < 0.05

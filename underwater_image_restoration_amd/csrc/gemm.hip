@@ -1333,6 +1333,86 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
     if (grp == 1 && t_prev >= 0) epilogue();
 }
 
+// ------------------------------------------------------------------------------------------
+// The UNet's 7x7 stem (cat([xt - cond, cond]) padded to 8 channels -> 64, DenoisingUNet_arch.py:60,127) on fp32 rows of
+// 8 channels: the generic im2col loader spends its time on per-tap index arithmetic (100 us, 260 TF/s at B = 8, 256^2).
+// Here one filter row is two MFMA k-steps -- 8 taps (the 8th with zero weights) x 8 channels, so a lane's 8-element
+// fragment piece is exactly ONE input pixel -- the 56 weight fragments live in LDS in fragment order, and a wave walks 8
+// output rows of a 16-pixel column strip with a rolling window of 7 input rows in registers (2 fragment loads per new row).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem7_mfma_kernel(const float* __restrict__ x, int lda, int H, int W,
+                                                         const bf16_t* __restrict__ wt, bf16_t* __restrict__ out, int ldo) {
+    constexpr int NF = 7 * 2 * 4;                                  // fragments: (ky, k-step s, channel tile j)
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[NF * 64 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    for (int i = tid; i < NF * 64; i += 256) {
+        const int f = i >> 6, l = i & 63, j = f & 3, s2 = (f >> 2) & 1, ky = f >> 3;
+        const int ch = chan_perm(j * 16 + (l & 15)), kx = 4 * s2 + (l >> 4);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+        if (kx < 7) v = *reinterpret_cast<const bf16x8*>(wt + (size_t)ch * 392 + (ky * 7 + kx) * 8);
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)i * 8]) = v;
+    }
+    __syncthreads();
+    const int b = blockIdx.z, x0 = blockIdx.x * 16, ybase = blockIdx.y * 32 + wave * 8;
+    const float* xb = x + (size_t)b * H * W * lda;
+    auto load_row = [&](int iy, bf16x8 (&dst)[2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ix = x0 + fr + 4 * s2 + fq - 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float* src = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * lda;
+            const float4 lo = load4(src), hi = load4(src + 4);
+            const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)(ok ? f[e] : 0.f);
+            dst[s2] = v;
+        }
+    };
+    bf16x8 rows[7][2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) load_row(ybase - 3 + k, rows[k]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = ybase + r;
+        if (y < H) {                                                // wave-uniform
+            load_row(y + 3, rows[(r + 6) % 7]);
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)(((ky * 2 + s2) * 4 + j) * 64 + lane) * 8]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, rows[(r + ky) % 7][s2], acc[j], 0, 0, 0);
+                    }
+            if (x0 + fr < W) {
+                bf16_t* op = out + ((size_t)(b * H + y) * W + x0 + fr) * ldo + fq * 16;
+#pragma unroll
+                for (int jp = 0; jp < 4; jp += 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)acc[jp][e]; o[4 + e] = (bf16_t)acc[jp + 1][e]; }
+                    *reinterpret_cast<bf16x8*>(op + jp * 4) = o;
+                }
+            }
+        }
+    }
+}
+
+static bool stem7_eligible(const uwir_gemm_args& g) {
+    return g.compute == UWIR_BF16 && g.KH == 7 && g.KW == 7 && g.stride == 1 && g.pad == 3 && g.C == 8 && g.N == 64 &&
+           g.a_dtype == UWIR_F32 && g.lda % 4 == 0 && g.ups == 0 && g.OH == g.H && g.OW == g.W && !g.a_scale && !g.bias &&
+           !g.batch_bias && !g.batch_scale && g.act == UWIR_ACT_NONE && !g.res && !g.col_scale && !g.blend_out &&
+           g.store_mode == 0 && g.out && g.out_dtype == UWIR_BF16 && g.ldo % 8 == 0 && ((uintptr_t)g.out & 15) == 0 &&
+           ((uintptr_t)g.A & 15) == 0 && g.B <= 65535 && ceil_div(g.H, 32) <= 65535;
+}
+
 static int g_conv_dma = 1;    // tools/: uwir_conv_variant bits 3-5: 0 default, 1 DMA conv off, 2.. forced tile / ring shapes
 static bool conv_dma_eligible(const uwir_gemm_args& g, int K) {
     // 32-bit byte offsets from the tensor bases; weights in whole 64-channel blocks; no prologue affine.  C = 64 (two
@@ -1550,6 +1630,12 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.nblocks = 0;
     p.splitk = 1;
     hipStream_t s = (hipStream_t)stream;
+    if (stem7_eligible(g)) {
+        hipLaunchKernelGGL(stem7_mfma_kernel, dim3(ceil_div(g.W, 16), ceil_div(g.H, 32), g.B), dim3(256), 0, s,
+                           (const float*)g.A, g.lda, g.H, g.W, (const bf16_t*)g.Wt, (bf16_t*)g.out, g.ldo);
+        UWIR_LAUNCH_CHECK("conv_gemm(stem 7x7)");
+        return UWIR_OK;
+    }
     if (halo_eligible(g)) {
         if (g_conv_dma && conv_dma_eligible(g, p.K)) return launch_conv_dma(p, s);
         if (g.a_dtype == UWIR_F32) return launch_halo<float>(p, s);
