@@ -133,7 +133,9 @@ typedef struct uwir_gemm_args {
     void* out;               /* [M, ldo] out_dtype (may be NULL when only blend_out is wanted) */
     int out_dtype, ldo;
     int store_mode;          /* 0: row m; 1: depth-to-space 2x2 (ConvTranspose2d k=2,s=2): N = 4*Cout,
-                                n = (dy*2+dx)*Cout + co goes to pixel (b, 2*oy+dy, 2*ox+dx), channel co */
+                                n = (dy*2+dx)*Cout + co goes to pixel (b, 2*oy+dy, 2*ox+dx), channel co;
+                                2: GEGLU (U/attention.py:37-44 fused into its projection): weight rows come in groups
+                                of 16 = 8 value rows then their 8 gate rows, out [M, N/2] = value * gelu(gate) */
     const float* blend_t;    /* optional gate blend (S/wfi_gate.py:44): blend_out = v*t + (1-v)*f, */
     const float* blend_f;    /* v = epilogue value, t/f/blend_out fp32 with strides ld_blend_in / ld_blend_out */
     int ld_blend_in;

@@ -965,3 +965,26 @@ def test_unet_stem_7x7_mfma(ops):
     ops.conv_gemm(to_rows(x), wd, o32, B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
     assert rel(from_rows(o32, b, h, w), ref) < 1e-4
     assert float((out[:, n:].float() - o32).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_gemm_geglu_store(ops, prec):
+    """GEGLU (attention.py:37-44) in the projection's epilogue: weight rows in groups of 8 values + their 8 gates, output
+    [M, F] = value * gelu(gate); must equal the projection followed by the stand-alone geglu kernel."""
+    g = torch.Generator().manual_seed(93)
+    M, K, F_ = 300, 64, 96
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(2 * F_, K, generator=g) / 8
+    b = torch.randn(2 * F_, generator=g)
+    pair = lambda t: torch.stack([t[:F_].reshape(F_ // 8, 8, *t.shape[1:]), t[F_:].reshape(F_ // 8, 8, *t.shape[1:])], 1).reshape(t.shape)
+    dt = _wdt(prec)
+    xd, wd = x.to(dt).cuda(), pair(w).to(dt).cuda().contiguous()
+    out = torch.full((M, F_ + 8), 2.0, device="cuda", dtype=dt)
+    ops.conv_gemm(xd, wd, out[:, :F_], B=1, H=1, W=M, C_=K, N=2 * F_, bias=pair(b).cuda().contiguous(), store_mode=2)
+    h = xd.double().cpu() @ w.to(dt).double().T + b.double()
+    ref = h[:, :F_] * F.gelu(h[:, F_:])
+    e, r = err(out[:, :F_], ref), rel(out[:, :F_].float().cpu(), ref)
+    print(f"\n[geglu store {prec}] max abs {e:.3e} rel {r:.3e} (|ref|max {float(ref.abs().max()):.2f})")
+    assert (e < 2e-5 if prec == "fp32" else r < 5e-3) and float(out[:, F_:].float().min()) == 2.0
+    with pytest.raises(Exception):
+        ops.conv_gemm(xd, wd, out[:, :F_], B=1, H=1, W=M, C_=K, N=2 * F_, store_mode=2, act=ops.ACT_GELU)

@@ -266,6 +266,29 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
         if (!g.out) continue;
         // bf16 rows, plain layout: two 16-byte stores cover the lane's 16 channels (when 8-channel groups are whole
         // and the row base is 16-byte aligned); everything else goes out as 4-channel pieces
+        if (EPI == EPI_FULL && g.store_mode == 2) {
+            // GEGLU pairs: the lane's 16 channels are 8 values then their 8 gates (weight rows ordered that way by the
+            // caller): out[m, (n_base + fq*16) / 2 + jj*4 + e] = value * gelu(gate), exact (erf) GELU
+            const int n = n_base + fq * 16;
+            if (n < N) {
+                float o8[8];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o8[jj * 4 + e] = vv[jj][e] * act_apply(vv[jj + 2][e], UWIR_ACT_GELU);
+                const size_t off = out_row * g.ldo + n / 2;
+                if (g.out_dtype == UWIR_BF16) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)o8[e];
+                    *reinterpret_cast<bf16x8*>((bf16_t*)g.out + off) = o;
+                } else {
+                    store4((float*)g.out + off, make_float4(o8[0], o8[1], o8[2], o8[3]));
+                    store4((float*)g.out + off + 4, make_float4(o8[4], o8[5], o8[6], o8[7]));
+                }
+            }
+            continue;
+        }
         const bool wide = g.out_dtype == UWIR_BF16 && g.store_mode == 0 && (N % 8 == 0) && (g.ldo % 8 == 0) &&
                           (((uintptr_t)g.out & 15) == 0);
 #pragma unroll
@@ -1609,13 +1632,17 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     UWIR_CHECK(!g.res || ((uintptr_t)g.res & (g.res_dtype == UWIR_BF16 ? 7 : 15)) == 0, "conv_gemm: res must be 16-byte (fp32) / 8-byte (bf16) aligned");
     UWIR_CHECK(!g.blend_out || (g.blend_t && g.blend_f && g.ld_blend_in % 4 == 0 && g.ld_blend_out % 4 == 0),
                "conv_gemm: bad blend arguments");
-    UWIR_CHECK(g.store_mode == 0 || g.store_mode == 1, "conv_gemm: bad store_mode");
+    UWIR_CHECK(g.store_mode >= 0 && g.store_mode <= 2, "conv_gemm: bad store_mode");
     if (g.out) {
         UWIR_CHECK(g.out_dtype == UWIR_F32 || g.out_dtype == UWIR_BF16, "conv_gemm: bad out dtype");
         UWIR_CHECK(g.ldo % 4 == 0, "conv_gemm: ldo must be a multiple of 4");
         if (g.store_mode == 1) {
             UWIR_CHECK(g.N % 16 == 0 && g.ldo >= g.N / 4 && !g.res && !g.blend_out,
                        "conv_gemm: depth-to-space needs N %% 16 == 0 and no residual/blend");
+        } else if (g.store_mode == 2) {
+            UWIR_CHECK(g.N % 16 == 0 && g.ldo >= g.N / 2 && g.ldo % 8 == 0 && ((uintptr_t)g.out & 15) == 0 && !g.res &&
+                           !g.blend_out && g.act == UWIR_ACT_NONE && !g.col_scale,
+                       "conv_gemm: GEGLU store needs N %% 16 == 0, 16-byte aligned rows of N / 2 and a plain bias epilogue");
         } else {
             UWIR_CHECK(g.ldo >= g.N, "conv_gemm: ldo < N");
         }

@@ -128,6 +128,12 @@ class ConditionalUNet(nn.Module):
 
         ov_w, ov_b, ov_off = [], [], [0]
 
+        def geglu_rows(w: torch.Tensor) -> torch.Tensor:
+            # [value rows | gate rows] -> groups of 16 = 8 value rows then their 8 gate rows (conv_gemm store_mode 2)
+            F_ = w.shape[0] // 2
+            return torch.stack([w[:F_].reshape(F_ // 8, 8, *w.shape[1:]), w[F_:].reshape(F_ // 8, 8, *w.shape[1:])],
+                               dim=1).reshape(w.shape)
+
         def attn(p: str) -> dict:
             a: dict = {"g_pre": vec(sd[p + "fn.norm.g"])}
             f = p + "fn.fn."
@@ -153,7 +159,8 @@ class ConditionalUNet(nn.Module):
                      w_o1=sd[t + "attn1.to_out.0.weight"].to(wdt).contiguous(), b_o1=vec(sd[t + "attn1.to_out.0.bias"]),
                      n1=(vec(sd[t + "norm1.weight"]), vec(sd[t + "norm1.bias"])),
                      n3=(vec(sd[t + "norm3.weight"]), vec(sd[t + "norm3.bias"])),
-                     w_ff0=sd[t + "ff.net.0.proj.weight"].to(wdt).contiguous(), b_ff0=vec(sd[t + "ff.net.0.proj.bias"]),
+                     w_ff0=geglu_rows(sd[t + "ff.net.0.proj.weight"]).to(wdt).contiguous(),
+                     b_ff0=geglu_rows(sd[t + "ff.net.0.proj.bias"]).to(f32).contiguous(),
                      w_ff2=sd[t + "ff.net.2.weight"].to(wdt).contiguous(), b_ff2=vec(sd[t + "ff.net.2.bias"]),
                      w_pout=conv(sd[f + "proj_out.weight"]), b_pout=vec(sd[f + "proj_out.bias"]))
             return a
@@ -282,13 +289,12 @@ class ConditionalUNet(nn.Module):
         o = a["ov_off"]
         ops.conv_gemm(att, a["w_o1"], t1, B=B, H=H, W=W, C_=dim, N=dim, bias=a["b_o1"], batch_bias=u_all[:, o:o + dim], res=t0)
         ops.ln_rows(t1, a["n3"][0], a["n3"][1], h, 1e-5)
-        ffh = self._buf(tag + "ffh", M, 8 * dim, adt, dev)
-        ops.conv_gemm(h, a["w_ff0"], ffh, B=B, H=H, W=W, C_=dim, N=8 * dim, bias=a["b_ff0"])
-        gg = self._buf(tag + "gg", M, 4 * dim, adt, dev)
-        ops.geglu(ffh, gg)
-        ops.conv_gemm(gg, a["w_ff2"], t0, B=B, H=H, W=W, C_=4 * dim, N=dim, bias=a["b_ff2"], res=t1)   # t0 is dead: reuse
+        gg = self._buf(tag + "gg", M, 4 * dim, adt, dev)     # GEGLU in the projection's epilogue (rows paired by _build_pack)
+        ops.conv_gemm(h, a["w_ff0"], gg, B=B, H=H, W=W, C_=dim, N=8 * dim, bias=a["b_ff0"], store_mode=2)
+        t2 = self._buf(tag + "t2", M, dim, adt, dev)     # feeds proj_out only: MFMA-operand dtype (bf16 rows take the LDS-DMA GEMM)
+        ops.conv_gemm(gg, a["w_ff2"], t2, B=B, H=H, W=W, C_=4 * dim, N=dim, bias=a["b_ff2"], res=t1)
         y = self._buf(tag + "y", M, dim, f32, dev)
-        ops.conv_gemm(t0, a["w_pout"], y, B=B, H=H, W=W, C_=dim, N=dim, bias=a["b_pout"], res=xn)      # ST: + x_in
+        ops.conv_gemm(t2, a["w_pout"], y, B=B, H=H, W=W, C_=dim, N=dim, bias=a["b_pout"], res=xn)      # ST: + x_in
         ops.add_rows(y, x, out)                                                                          # Residual: + x
 
     # ------------------------------------------------------------------ forward
