@@ -38,7 +38,7 @@ int uwir_version(void);
  * large-K 1x1 GEMMs on the 128 x 128 kernel instead of the 256 x 192 one (same sums in another order), bit 2 keeps
  * the radix-2 FFT line kernel instead of the radix-4 one (same transform, another summation order), bits 3-5 pick the
  * 3x3 conv kernel for bf16 rows (0 = by shape, the default; 1 = the register-staged halo kernel; 2 / 3 / 4 = the LDS-DMA
- * kernel with 8-row tiles and a ring of 4 / 3, or 16-row tiles and a ring of 2; 7 = by shape but never the
+ * kernel with 8-row tiles and a ring of 4 / 3, or 16-row tiles and a ring of 2; 5 = 16-row tiles, ring of 3; 7 = by shape but never the
  * resident-weight kernel; identical results for every value). */
 void uwir_conv_variant(int variant);
 /* Test / measurement switch, no counterpart in the reference: tiles walked by one block of the pipelined depthwise

@@ -952,12 +952,17 @@ __device__ __forceinline__ void cd_dma16(const void* sbase, unsigned voff, unsig
 }
 template <int N> __device__ __forceinline__ void cd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TH, int NS>
+// PWL = LDS rows per image row of the halo tile: 20 (swizzle period 2 along the tile rows, every wave issues the same
+// number of halo pieces) or 18 (no padding rows: period 4, 21 pieces for 16 + 2 rows -- wave 0 issues one more than the
+// others, so its counted waits differ by one -- which is what lets 16-row tiles keep a ring of 3 at two blocks per CU).
+template <int TH, int NS, int PWL>
 __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
-    constexpr int BN = 64, TM = TH / 4, TN = 4;
-    constexpr int A_ROWS = ((TH + 2) * CD_PWL + 63) / 64 * 64;   // LDS rows of one activation buffer: whole rounds of 4 x 16
-    constexpr int A_IT = A_ROWS / 64, W_IT = 3;                  // DMA instructions per thread: per chunk / per stage
-    constexpr int A_BYTES = A_ROWS * 64, W_BYTES = 3 * BN * 64;
+    constexpr int BN = 64, TM = TH / 4, TN = 4, KV = PWL == 20 ? 2 : 4;
+    constexpr int A_PIECES = PWL == 20 ? ((TH + 2) * PWL + 63) / 64 * 4 : ((TH + 2) * PWL + 15) / 16;   // 16-row DMA pieces
+    constexpr int A_IT = (A_PIECES + 3) / 4, W_IT = 3;           // DMA instructions per thread (wave 0): per chunk / per stage
+    constexpr bool RAGGED = A_PIECES % 4 != 0;                   // waves 1-3 issue A_IT - 1 pieces
+    static_assert(!RAGGED || A_PIECES % 4 == 1, "only wave 0 may carry the extra piece");
+    constexpr int A_BYTES = A_PIECES * 1024, W_BYTES = 3 * BN * 64;
     __shared__ __attribute__((aligned(1024))) char smem[2 * A_BYTES + NS * W_BYTES];
 
     const uwir_gemm_args& g = p.a;
@@ -981,10 +986,10 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
     unsigned a_off[A_IT], a_pad = 0;   // bit it of a_pad: this lane's piece is padding of a pixel that is read
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int rho = (it * 4 + wave) * 16 + (lane >> 2);
-        const int py = rho / CD_PWL, px = rho % CD_PWL;
+        const int rho = (it * 4 + wave) * 16 + (lane >> 2);       // (a piece past A_PIECES is never issued)
+        const int py = rho / PWL, px = rho % PWL;
         const int iy = y0 + py - 1, ix = x0 + px - 1;
-        const bool used = py < TH + 2 && px < HC_PW;
+        const bool used = py < TH + 2 && px < HC_PW && it * 4 + wave < A_PIECES;
         const bool in = iy >= 0 && iy < OH && ix >= 0 && ix < OW;
         if (used && !in) a_pad |= 1u << it;
         const int cy = used && in ? iy : 0, cx = used && in ? ix : 0;
@@ -1014,7 +1019,8 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
         const char* ab = a_base + (size_t)c * (HC_BK * 2);
         const unsigned dst = lds0 + (c & 1) * A_BYTES + wave * 1024;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) cd_dma16(ab, a_off[it], dst + it * 4096);
+        for (int it = 0; it < A_IT; ++it)
+            if (!RAGGED || it + 1 < A_IT || wave == 0) cd_dma16(ab, a_off[it], dst + it * 4096);   // wave-uniform
     };
 
     f32x4 acc[TM][TN];
@@ -1024,12 +1030,12 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     const int wr0 = wave * TM;
-    int a_rd[HC_TG][2];                                            // byte offsets into an activation buffer, by (tap, parity of i + ky)
+    int a_rd[HC_TG][KV];                                           // byte offsets into an activation buffer, by (tap, (i + ky) % KV)
 #pragma unroll
     for (int t = 0; t < HC_TG; ++t) {
-        const int r = wr0 * CD_PWL + fr + t;
-        a_rd[t][0] = r * 64 + (fq ^ hc_swz(r)) * 16;
-        a_rd[t][1] = r * 64 + (fq ^ hc_swz(r) ^ 2) * 16;
+        const int r = wr0 * PWL + fr + t;
+#pragma unroll
+        for (int kk = 0; kk < KV; ++kk) a_rd[t][kk] = r * 64 + (fq ^ hc_swz(r + PWL * kk)) * 16;   // swizzle of row r + PWL k: period KV
     }
     const int w_rd = fr * 64 + (fq ^ hc_swz(fr)) * 16;
 
@@ -1040,7 +1046,7 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + grp) & 1] + (i + grp) * (CD_PWL * 64));
+                fa[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + grp) % KV] + (i + grp) * (PWL * 64));
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sw + w_rd + (tapl * BN + j * 16) * 64);
 #pragma unroll
@@ -1056,10 +1062,14 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
     // and last chunk.
     auto stage = [&](auto grp_tag, int c, bool last) {
         constexpr int grp = decltype(grp_tag)::value;
-        constexpr int steady = grp == 0 ? W_IT * (NS - 2) : (grp == 1 || NS >= 3) ? W_IT * (NS - 2) + A_IT : 0;
+        constexpr bool with_a = grp != 0 && (grp == 1 || NS >= 3);   // the next chunk's halo pieces are younger than stage s
+        constexpr int steady = W_IT * (NS - 2) + (with_a ? A_IT : 0);
         constexpr int tail = grp == 0 ? W_IT * (NS - 2 < 2 ? NS - 2 : 2) : grp == 1 ? W_IT * (NS - 2 < 1 ? NS - 2 : 1) : 0;
+        constexpr int steady_w = steady - ((with_a && RAGGED) ? 1 : 0) < 0 ? 0 : steady - ((with_a && RAGGED) ? 1 : 0);
         const int s = 3 * c + grp;
-        if (last) cd_wait_vm<tail>(); else cd_wait_vm<steady>();
+        if (last) cd_wait_vm<tail>();
+        else if (wave == 0) cd_wait_vm<steady>();
+        else cd_wait_vm<steady_w>();
         if (grp == 0 && a_pad) {                                   // zero the padding pieces this lane's DMA just wrote
             char* mine = smem + (c & 1) * A_BYTES + wave * 1024 + lane * 16;
 #pragma unroll
@@ -1506,19 +1516,21 @@ static int launch_conv_dma(const GemmP& p0, hipStream_t stream) {
     // (8 rows, ring 3) / 54.5 us; 128^2 C192->128 75.4 / 67.8 / 63.3; nearest-2x 32^2 -> 64^2 C512->256 77 / 70 / 60.6 --
     // below that 8-row tiles with a ring of 3: 32^2 C512->512 50.3 / 41.7 / 44.9, 32^2 C256->256 22.4 / 17.4 / 27.
     int shape = g_conv_dma == 7 ? 1 : g_conv_dma; // forced by tools/: 2 = 8 rows, ring 4; 3 = 8 rows, ring 3; 4 = 16 rows, ring 2;
+                                                  // 5 = 16 rows, ring 3 on unpadded (18-row pitch) halo tiles;
                                                   // 7 = automatic, but C = 64 on the ring kernel instead of the resident-weight one
     if (shape < 2) {
         const long long nb16 = (long long)p.a.B * ceil_div(p.a.OH, 16) * ceil_div(p.a.OW, HC_TW) * (p.a.N / 64);
-        shape = nb16 >= 512 ? 4 : 3;
+        shape = nb16 >= 512 ? 5 : 3;   // 16-row tiles: ring of 3 on 18-row-pitch halo tiles (1-4 % over the ring of 2 on pitch 20)
     }
-    const int th = shape == 4 ? 16 : 8;
+    const int th = shape >= 4 ? 16 : 8;
     p.tiles_n = p.a.N / 64;
     const long long nb = (long long)p.a.B * ceil_div(p.a.OH, th) * ceil_div(p.a.OW, HC_TW) * p.tiles_n;
     if (nb > 0x7fffffffLL) return uwir_set_error(UWIR_EINVAL, "conv_gemm: grid too large");
     p.nblocks = (int)nb;
-    if (shape == 2) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 4>), dim3(p.nblocks), dim3(256), 0, stream, p);
-    else if (shape == 3) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 3>), dim3(p.nblocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_dma_kernel<16, 2>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    if (shape == 2) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 4, 20>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else if (shape == 3) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 3, 20>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else if (shape == 5) hipLaunchKernelGGL((conv3x3_dma_kernel<16, 3, 18>), dim3(p.nblocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_dma_kernel<16, 2, 20>), dim3(p.nblocks), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("conv_gemm(dma)");
     return UWIR_OK;
 }
