@@ -372,8 +372,10 @@ __global__ void __launch_bounds__(256) la_apply_fused_kernel(const TX* __restric
 
 // ------------------------------------------------------------------------------------------
 static int la_block_chunks(int B, int n, int* rows_per_chunk) {
-    // about 1024 blocks over the batch, chunks a multiple of the 64-row tile, at most 256 chunks
-    int want = (1024 + B - 1) / B;
+    // at most 768 blocks over the batch (3 resident blocks per CU at 138 VGPRs: ONE round of blocks -- 1024 equal blocks
+    // on 768 slots take two), chunks a multiple of the 64-row tile, at most 256 chunks
+    int want = 768 / B;
+    if (want < 1) want = 1;
     int tiles = ceil_div(n, LF_TR);
     int nchunks = want < tiles ? want : tiles;
     if (nchunks > 256) nchunks = 256;
@@ -413,8 +415,9 @@ extern "C" int uwir_linattn_block(const void* x, int io_dtype, int ldx, int B, i
     const bf16_t* wo = (const bf16_t*)w_out;
     const float inv_n_scale = (float)(1.0 / ((double)n * sqrt((double)LF_D)));   // q * D^-0.5 and v / n folded into ctx
     // row groups per wave in pass 2: amortise the block's LDS weight image, but keep >= ~768 blocks on the 256 CUs
+    // (rounded UP: one round of at most 768 blocks, not a full round and a nearly empty one)
     long long quads = (long long)B * ceil_div(n, 128);
-    int rgw = (int)(quads / 768);
+    int rgw = (int)((quads + 767) / 768);
     rgw = rgw < 1 ? 1 : (rgw > 8 ? 8 : rgw);
 #define LA_LAUNCH(DIM_, TX_)                                                                                               \
     hipLaunchKernelGGL((la_kv_fused_kernel<DIM_, TX_>), dim3(nchunks, B), dim3(256), 0, s, (const TX_*)x, ldx, n, rpc,     \
