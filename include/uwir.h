@@ -173,7 +173,7 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
 /* ---- global multi-head attention, flash style (no n x n matrix) ----------------------------
  * S/wtb.py:94-115 (one V) and S/cfc.py:24-39 (one softmax(QK^T/sqrt(hd)) applied to two V's).
  * q,k,v1,v2: [B*n, ld*] matrices (dtype), head h occupies columns [h*hd, (h+1)*hd).
- * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 64.
+ * o1/o2 likewise (out_dtype).  v2/o2 may be NULL.  hd % 4 == 0, hd <= 128 (above 64 a v2 / o2 pair runs as two passes).
  * scale = 1/sqrt(hd) normally; scale == 0 means "q is already multiplied by (1/sqrt(hd))*log2(e)" (the producing
  * GEMM applied it through col_scale), which saves one bf16 rounding of q.
  * workspace (optional, >= uwir_flash_attn_workspace_bytes(B, n, heads), 4-byte aligned): enables the bf16 fast path --

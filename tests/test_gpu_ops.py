@@ -342,7 +342,8 @@ def _attn_ref(q, k, vs, heads, hd):
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("cfg", [(2, 16, 12, 16, 1), (1, 50, 12, 16, 1), (1, 1000, 3, 32, 1), (2, 200, 2, 64, 1),
                                  (1, 1, 4, 16, 2), (2, 333, 4, 16, 2), (1, 129, 4, 32, 2), (1, 257, 4, 64, 2),
-                                 (1, 70, 12, 4, 1), (1, 70, 4, 8, 2), (1, 4096, 2, 16, 1)])
+                                 (1, 70, 12, 4, 1), (1, 70, 4, 8, 2), (1, 4096, 2, 16, 1),
+                                 (1, 300, 2, 128, 1), (2, 130, 3, 96, 2), (1, 1100, 2, 128, 2)])   # wide heads: hd > 64
 def test_flash_attn(ops, prec, cfg):
     b, n, heads, hd, nv = cfg
     g = torch.Generator().manual_seed(7)

@@ -115,3 +115,24 @@ def test_conditioning_schedule_is_bit_identical(sde_mod, precision):
     assert torch.equal(in_sched, unet(xt, mu, 2.0, text_context=tc, image_context=ic))
     assert torch.equal(other_c, in_sched) and torch.equal(tens_t, in_sched)
     assert torch.equal(other_t, unet(xt, mu, 3.0, text_context=tc, image_context=ic))
+
+
+def test_save_states_writes_the_reference_files(sde_mod, tmp_path):
+    """sde_utils.py:269-275: every T // 100 steps the two channel halves of the state, side by side, as state_{idx}.png."""
+    from PIL import Image
+    import numpy as np
+    gen = torch.Generator().manual_seed(8)
+    mu = torch.rand(2, 6, 8, 12, generator=gen).cuda()
+    sde = sde_mod.IRSDE(max_sigma=50, T=100, schedule="cosine", eps=0.005, device="cuda")
+    sde.set_mu(mu)
+    sde.set_model(lambda x, m, t, **kw: torch.zeros_like(x))
+    d = str(tmp_path / "states")
+    out = sde.reverse_ode(mu + 0.1, save_states=True, save_dir=d)
+    files = sorted(os.listdir(d))
+    assert len(files) == 100 and "state_1.png" in files and "state_100.png" in files
+    last = np.asarray(Image.open(os.path.join(d, "state_1.png")))          # written after the final step (t = 1)
+    exp = sde_mod.state_grid_uint8(torch.cat(out.chunk(2, dim=1), dim=3)).numpy()
+    assert last.shape == (8 + 4, 2 * (24 + 2) + 2, 3) and np.array_equal(last, exp)
+    with pytest.raises(RuntimeError):                                        # 3 channels do not split in two halves
+        sde.set_mu(mu[:, :3].contiguous())
+        sde.reverse_ode(mu[:, :3].contiguous(), save_states=True, save_dir=d)

@@ -124,3 +124,32 @@ def test_student_non_power_of_two_maps_match_oracle(hw):
     e = float((out.cpu().double() - ref).abs().max())
     print(f"\n[student {hw[0]}x{hw[1]} fp32] max abs err vs fp64 oracle {e:.3e}")
     assert e < 1e-4
+
+
+@pytest.mark.parametrize("mk_extra", [dict(base_channels=128, num_levels=3), dict(base_channels=32, num_levels=5)])
+def test_student_wide_heads_match_oracle(mk_extra):
+    """Students wider / deeper than the reference's default reach head_dim 128 at their last level (base 128, 3 levels:
+    hd 32 / 64 / 128; base 32, 5 levels: hd 8 .. 128): the attention kernels take hd <= 128 (the CFC's two-V pair as two
+    passes above 64).  fp32 against the fp64 oracle, same bound; bf16 PSNR floor."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import student_ref as R
+    from tests.helpers import psnr
+    from underwater_image_restoration_amd.student import NAFNetWFIGate
+    from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs
+    mk = dict(blocks_per_level=1, cond_dim=20, num_masks=10, num_degradation_types=5, **mk_extra)
+    sd = synth_state_dict(student_param_shapes(**mk), seed=31)
+    x, z, m = synth_student_inputs(1, 64, 64, 20, 10, mask_hw=(7, 7), seed=32)
+    with torch.no_grad():
+        ref = R.student_forward({k: v.double() for k, v in sd.items()}, x.double(), z.double(), m.double(),
+                                num_levels=mk["num_levels"], blocks_per_level=1)[0]
+    for prec in ("fp32", "bf16"):
+        model = NAFNetWFIGate(**mk, precision=prec)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        out = model(x.cuda(), z.cuda(), m.cuda())[0].cpu()
+        e, p = float((out.double() - ref).abs().max()), psnr(out, ref)
+        print(f"\n[student {mk_extra} {prec}] max abs err vs fp64 oracle {e:.3e}, PSNR {p:.1f} dB")
+        assert e < 1e-4 if prec == "fp32" else p >= 50.0
+    with pytest.raises(ValueError):
+        NAFNetWFIGate(base_channels=256, num_levels=3)

@@ -47,3 +47,22 @@ def test_trajectories_match_reference(golden_dir, mode):
 def test_unknown_schedule_raises():
     with pytest.raises(ValueError):
         S.theta_schedule("nope", 10)
+
+
+def test_state_grid_matches_torchvision_defaults():
+    """save_states writes torchvision.utils.save_image(x, normalize=False) files; torchvision is not installed here, so its
+    documented defaults are restated (grid of 8 per row, 2 px zero padding, x * 255 + 0.5 clamped): shapes, border, cell
+    placement and quantisation of the restatement."""
+    from underwater_image_restoration_amd.sde import state_grid_uint8
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(11, 3, 5, 7, generator=g) * 1.4 - 0.2          # values outside [0, 1] clamp
+    grid = state_grid_uint8(x)
+    assert grid.shape == (2 * 7 + 2, 8 * 9 + 2, 3) and grid.dtype == torch.uint8
+    assert int(grid[:2].max()) == 0 and int(grid[:, :2].max()) == 0 and int(grid[7:9].max()) == 0     # padding lines
+    cell = grid[2 + 7:2 + 7 + 5, 2 + 2 * 9:2 + 2 * 9 + 7]                                                # image 10: row 1, col 2
+    exp = (x[10] * 255 + 0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8)
+    assert torch.equal(cell, exp)
+    assert int(grid[9:, 2 + 3 * 9:].max()) == 0                                                          # cells 11.. stay empty
+    one = state_grid_uint8(x[:1])
+    assert one.shape == (5, 7, 3) and torch.equal(one, (x[0] * 255 + 0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8))
+    assert state_grid_uint8(x[:2, :1]).shape == (5 + 4, 2 * 9 + 2, 3)                                    # 1 channel -> 3

@@ -920,7 +920,8 @@ static int launch_attn_nv(const AttnP& p, int nv, int B, hipStream_t stream) {
     dim3 grid(ceil_div(p.n, 128), p.heads, B);
     probe_mark(0, stream);
     if (nv == 1) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 1, 1, 0>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2, 1, 0>), grid, dim3(256), 0, stream, p);
+    else if constexpr (HD <= 64) hipLaunchKernelGGL((flash_attn_kernel<T, HD, 2, 1, 0>), grid, dim3(256), 0, stream, p);
+    else return uwir_set_error(UWIR_EUNSUPPORTED, "flash_attn: two value streams at head_dim > 64 run as two calls");
     probe_mark(1, stream);
     UWIR_LAUNCH_CHECK("flash_attn");
     return UWIR_OK;
@@ -930,7 +931,8 @@ template <typename T>
 static int launch_attn(const AttnP& p, int nv, int B, hipStream_t stream) {
     if (p.hd <= 16) return launch_attn_nv<T, 16>(p, nv, B, stream);
     if (p.hd <= 32) return launch_attn_nv<T, 32>(p, nv, B, stream);
-    return launch_attn_nv<T, 64>(p, nv, B, stream);
+    if (p.hd <= 64) return launch_attn_nv<T, 64>(p, nv, B, stream);
+    return launch_attn_nv<T, 128>(p, nv, B, stream);   // one value stream only (the V^T tiles of two would not fit LDS in fp32)
 }
 
 extern "C" size_t uwir_flash_attn_workspace_bytes(int B, int n, int heads) { return attn_hdr_bytes(B, n, heads); }
@@ -946,7 +948,16 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     UWIR_CHECK(q && k && v1 && o1, "flash_attn: null pointer");
     UWIR_CHECK((v2 == nullptr) == (o2 == nullptr), "flash_attn: v2 and o2 must come together");
     UWIR_CHECK(B > 0 && B <= 65535 && heads > 0 && heads <= 65535 && n > 0, "flash_attn: bad shape");
-    UWIR_CHECK(hd > 0 && hd <= 64 && hd % 4 == 0, "flash_attn: head_dim must be a multiple of 4, <= 64 (got %d)", hd);
+    UWIR_CHECK(hd > 0 && hd <= 128 && hd % 4 == 0, "flash_attn: head_dim must be a multiple of 4, <= 128 (got %d)", hd);
+    if (hd > 64 && v2) {
+        // wide heads (a student wider / deeper than the reference's default): the shared-softmax pair runs as two
+        // single-V attentions over the same q, k (same results; QK^T and the softmax are computed twice)
+        int rc = uwir_flash_attn(q, ldq, k, ldk, v1, ldv1, nullptr, 0, dtype, B, n, heads, hd, scale, o1, ldo1, nullptr, 0,
+                                 out_dtype, workspace, workspace_bytes, stream);
+        if (rc != UWIR_OK) return rc;
+        return uwir_flash_attn(q, ldq, k, ldk, v2, ldv2, nullptr, 0, dtype, B, n, heads, hd, scale, o2, ldo2, nullptr, 0,
+                               out_dtype, workspace, workspace_bytes, stream);
+    }
     UWIR_CHECK(dtype == UWIR_F32 || dtype == UWIR_BF16, "flash_attn: bad dtype");
     UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "flash_attn: bad out dtype");
     int w = heads * hd;

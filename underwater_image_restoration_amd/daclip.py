@@ -52,8 +52,8 @@ class DaCLIPVision(nn.Module):
         if width % heads:
             raise ValueError("embed_dim must be divisible by num_heads")
         hd = width // heads
-        if hd % 4 or hd > 64:
-            raise ValueError("this build needs head_dim % 4 == 0 and head_dim <= 64")
+        if hd % 4 or hd > 128:
+            raise ValueError("this build needs head_dim % 4 == 0 and head_dim <= 128")
         if patch_size % 4 or image_size % patch_size or width % 8:
             raise ValueError("this build needs patch_size % 4 == 0, image_size % patch_size == 0, width % 8 == 0")
         if precision not in ("fp32", "bf16"):

@@ -6,17 +6,44 @@ loops ``reverse_sde / reverse_posterior / reverse_ode`` call the score model onc
 kernel (``uwir_sde_euler_step`` / ``uwir_sde_posterior_step``: 4 reads + 1 write per element instead of ~10
 elementwise launches).  Extra, optional argument: ``noise_tape`` ``(T,B,C,H,W)`` of N(0,1) draws (loop order) for
 reproducible trajectories; by default noise comes from ``torch.randn_like`` on the device like the reference.
-``save_states`` (PNG dumps through torchvision) is not supported.
+``save_states`` writes the same ``state_{idx}.png`` files as the reference (sde_utils.py:269-275: every T // 100 steps,
+the two channel halves of the state side by side) with ``torchvision.utils.save_image``'s defaults restated here
+(``state_grid_uint8``: grid of 8 per row, 2 px of zero padding, x * 255 + 0.5 clamped to uint8) and written through PIL;
+torchvision is not installed in this image, so the files are "parity unpinned" against it.
 """
 from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import Optional
 
 import torch
 
 from . import ops
+
+
+def state_grid_uint8(tensor: torch.Tensor, nrow: int = 8, padding: int = 2) -> torch.Tensor:
+    """torchvision.utils.make_grid + save_image's quantisation for a (B, C, H, W) batch with default arguments
+    (normalize=False, pad_value=0): -> (H', W', 3 or 1) uint8 on the CPU.  Single-channel batches are tripled like
+    make_grid does; a single image is returned without a border, also like make_grid."""
+    t = tensor.detach().float().cpu()
+    if t.dim() != 4:
+        raise ValueError("expected a (B, C, H, W) batch")
+    if t.shape[1] == 1:
+        t = t.expand(-1, 3, -1, -1)
+    B, C, H, W = t.shape
+    if B == 1:
+        grid = t[0]
+    else:
+        xmaps = min(nrow, B)
+        ymaps = int(math.ceil(B / xmaps))
+        hh, ww = H + padding, W + padding
+        grid = t.new_zeros(C, hh * ymaps + padding, ww * xmaps + padding)
+        for k in range(B):
+            y, x = k // xmaps, k % xmaps
+            grid[:, y * hh + padding:y * hh + padding + H, x * ww + padding:x * ww + padding + W] = t[k]
+    return grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)
 
 
 class IRSDE:
@@ -196,7 +223,21 @@ class IRSDE:
         return self.reverse_sde_step_from_noise(x, -score * self.sigma_bar(t), t, eps=False, score_weight=0.5)
 
     # ---- sampling loops (sde_utils.py:261-313)
-    def _loop(self, xt, T, mode, noise_tape, kwargs):
+    def _save_state(self, x, t: int, save_dir: str) -> None:
+        # sde_utils.py:269-275 ("only consider to save 100 images")
+        interval = self.T // 100
+        if interval == 0:
+            raise ZeroDivisionError("save_states needs T >= 100 (the reference computes t % (T // 100))")
+        if t % interval:
+            return
+        from PIL import Image
+        os.makedirs(save_dir, exist_ok=True)
+        x_l, x_r = x.chunk(2, dim=1)
+        img = state_grid_uint8(torch.cat([x_l, x_r], dim=3))   # (odd channel counts fail here, as in the reference)
+        arr = img.numpy()
+        Image.fromarray(arr if arr.shape[2] == 3 else arr[:, :, 0]).save(f"{save_dir}/state_{t // interval}.png")
+
+    def _loop(self, xt, T, mode, noise_tape, kwargs, save_dir=None):
         T = self.sample_T if T < 0 else T
         x = xt.clone().contiguous().float()
         # a ConditionalUNet of this package derives everything that depends on (t, contexts) alone for the whole loop in
@@ -215,21 +256,15 @@ class IRSDE:
                     x = self.reverse_sde_step_from_noise(x, pred, t, eps=eps, out=x)
                 else:
                     x = self.reverse_sde_step_from_noise(x, pred, t, eps=False, score_weight=0.5, out=x)
+                if save_dir is not None:
+                    self._save_state(x, t, save_dir)
         return x
 
     def reverse_sde(self, xt, T=-1, save_states=False, save_dir="sde_state", noise_tape=None, **kwargs):
-        self._no_save(save_states)
-        return self._loop(xt, T, "sde", noise_tape, kwargs)
+        return self._loop(xt, T, "sde", noise_tape, kwargs, save_dir if save_states else None)
 
     def reverse_posterior(self, xt, T=-1, save_states=False, save_dir="posterior_state", noise_tape=None, **kwargs):
-        self._no_save(save_states)
-        return self._loop(xt, T, "posterior", noise_tape, kwargs)
+        return self._loop(xt, T, "posterior", noise_tape, kwargs, save_dir if save_states else None)
 
     def reverse_ode(self, xt, T=-1, save_states=False, save_dir="ode_state", **kwargs):
-        self._no_save(save_states)
-        return self._loop(xt, T, "ode", None, kwargs)
-
-    @staticmethod
-    def _no_save(save_states):
-        if save_states:
-            raise NotImplementedError("save_states (PNG dumps via torchvision) is out of scope for the MI355X path")
+        return self._loop(xt, T, "ode", None, kwargs, save_dir if save_states else None)

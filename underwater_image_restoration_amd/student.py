@@ -49,8 +49,8 @@ class NAFNetWFIGate(nn.Module):
         if base_channels % 4 != 0 or (base_channels // 4) % 4 != 0:
             raise ValueError("channels must be divisible by num_heads.") if base_channels % 4 else ValueError(
                 "this build needs head_dim = base_channels/4 to be a multiple of 4")
-        if base_channels * 2 ** (num_levels - 1) // 4 > 64:
-            raise ValueError("head_dim > 64 is not supported by the attention kernel")
+        if base_channels * 2 ** (num_levels - 1) // 4 > 128:
+            raise ValueError("head_dim > 128 is not supported by the attention kernel")
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.in_channels, self.out_channels = in_channels, out_channels
