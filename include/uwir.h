@@ -52,13 +52,14 @@ const char* uwir_last_error(void);
 /* ---- S/dwt_fft.py:33-39 dwt2 -------------------------------------------------------------
  * x [B,H,W,C] fp32 (pixel stride ldx) -> ll [B,H/2,W/2,C] (stride ld_ll) and
  * hf [B,H/2,W/2,3C] = [lh|hl|hh] (stride ld_hf); odd trailing row/column dropped like the
- * reference's stride-2 valid conv.  C % 4 == 0. */
-int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, float* ll, int ld_ll, float* hf, int ld_hf,
-              uwir_stream_t stream);
+ * reference's stride-2 valid conv.  C % 4 == 0.  ll and hf are written as sub_dtype: fp32, or bf16 (the student's
+ * bf16 mode keeps its sub-band stream -- ll, hf and the WTB's residual rows -- in bf16; the Haar sums are fp32). */
+int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf, int ld_hf,
+              int sub_dtype, uwir_stream_t stream);
 
 /* ---- S/dwt_fft.py:42-58 idwt2 ------------------------------------------------------------
- * ll [B,h,w,C], hf [B,h,w,3C]=[lh|hl|hh] -> out [B,2h,2w,C]. */
-int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf, int B, int h, int w, int C, float* out,
+ * ll [B,h,w,C] fp32, hf [B,h,w,3C]=[lh|hl|hh] of hf_dtype (fp32 or bf16) -> out [B,2h,2w,C] fp32. */
+int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C, float* out,
                int ldo, uwir_stream_t stream);
 
 /* ---- S/utils.py:10-36 LayerNorm2d / AdaLayerNorm2d ------------------------------------------
@@ -68,9 +69,10 @@ int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf, int B, in
  * consumer kernel applies while loading x, optionally mean[b,c] (global average pool,
  * S/deg_head.py:20) and pooled[b,c] = spatial mean of the normalised map (= beta*(1+scale)+shift).  scale_shift [B, ss_ld] holds [scale(C)|shift(C)] per sample or is NULL
  * (plain LayerNorm2d).  gamma/beta NULL => statistics only (mean_out must be given).
- * workspace: >= uwir_ln2d_workspace_bytes(B,n,C) bytes.  C % 4 == 0. */
+ * workspace: >= uwir_ln2d_workspace_bytes(B,n,C) bytes.  C % 4 == 0.  x is fp32 or bf16 (x_dtype); sums are fp32 per
+ * block and fp64 across blocks either way. */
 size_t uwir_ln2d_workspace_bytes(int B, int n, int C);
-int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma, const float* beta,
+int uwir_ln2d_affine(const void* x, int x_dtype, int ldx, int B, int n, int C, float eps, const float* gamma, const float* beta,
                      const float* scale_shift, int ss_ld, float* a_out, float* s_out, float* mean_out,
                      float* pooled_out, void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 
@@ -84,13 +86,13 @@ int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, co
  * with separate workspaces.  The device is the one current at the call (the stream must belong to it). */
 #define UWIR_LN2D_NOALLOC_SCRATCH_BYTES (16u << 20)
 size_t uwir_ln2d_noalloc_max_bytes(void);
-int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+int uwir_ln2d_affine_noalloc(const void* x, int x_dtype, int ldx, int B, int n, int C, float eps, const float* gamma,
                              const float* beta, const float* scale_shift, int ss_ld, float* a_out, float* s_out,
                              float* mean_out, float* pooled_out, uwir_stream_t stream);
 
 /* ---- materialised form of the same norm (S/utils.py:18-36): out[m,c] = a[b,c]*x[m,c] + s[b,c], b = m / n, out fp32
  * or bf16.  For consumers that are better fed a ready bf16 operand (LDS-DMA GEMM path) than normalise-on-load. */
-int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
+int uwir_affine_cast(const void* x, int x_dtype, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
                      int out_dtype, int ldo, uwir_stream_t stream);
 
 /* ---- S/wtb.py:13-28,118-119 ChannelAttention folded into the residual ------------------------

@@ -989,3 +989,62 @@ def test_conv_gemm_geglu_store(ops, prec):
     assert (e < 2e-5 if prec == "fp32" else r < 5e-3) and float(out[:, F_:].float().min()) == 2.0
     with pytest.raises(Exception):
         ops.conv_gemm(xd, wd, out[:, :F_], B=1, H=1, W=M, C_=K, N=2 * F_, store_mode=2, act=ops.ACT_GELU)
+
+
+def test_bf16_subband_stream_variants(ops):
+    """The student's bf16 sub-band stream: dwt2 writing bf16 sub-bands, idwt2 reading bf16 hf, LayerNorm2d statistics and
+    the norm-and-cast pass on bf16 rows, the lean residual GEMM class starting from bf16 rows (plain and affine).  Each
+    against fp64 on the same (bf16-rounded where stored as bf16) values."""
+    g = torch.Generator().manual_seed(95)
+    bf = torch.bfloat16
+    b, c, h, w = 2, 8, 12, 20
+    x = torch.randn(b, c, h, w, generator=g)
+    ll, lh, hl, hh = R.haar_dwt2(x.double())
+    h2, w2 = h // 2, w // 2
+    dll = torch.full((b * h2 * w2, c + 8), 5.0, device="cuda", dtype=bf)
+    dhf = torch.empty(b * h2 * w2, 3 * c, device="cuda", dtype=bf)
+    ops.dwt2(to_rows(x), b, h, w, c, dll[:, :c], dhf)
+    assert torch.equal(from_rows(dll[:, :c].float(), b, h2, w2).cpu(), ll.float().to(bf).float()) or \
+        err(from_rows(dll[:, :c].float(), b, h2, w2), ll) < 2e-2
+    assert err(from_rows(dhf.float(), b, h2, w2), torch.cat([lh, hl, hh], 1)) < 2e-2 and float(dll[:, c:].float().min()) == 5.0
+    with pytest.raises(TypeError):
+        ops.dwt2(to_rows(x), b, h, w, c, dll[:, :c], dhf.float())
+    out = torch.empty(b * 4 * h2 * w2, c, device="cuda")
+    llf = to_rows(ll.float())
+    ops.idwt2(llf, dhf, b, h2, w2, c, out)
+    hfd = from_rows(dhf.float(), b, h2, w2).double().cpu()
+    assert err(from_rows(out, b, 2 * h2, 2 * w2), R.haar_idwt2(ll, hfd[:, :c], hfd[:, c:2 * c], hfd[:, 2 * c:])) < 1e-5
+    # LayerNorm2d statistics + folded affine on bf16 rows == on the fp32 rows holding the same values
+    B, n, C = 3, 700, 48
+    xr = (torch.randn(B * n, C, generator=g) * 2 + 0.5).to(bf)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    res = {}
+    for dt in (torch.float32, bf):
+        a, s, mean = (torch.empty(B, C, device="cuda") for _ in range(3))
+        ws = torch.empty(max(ops.ln2d_workspace_bytes(B, n, C) // 8, 1), dtype=torch.float64, device="cuda")
+        ops.ln2d_affine(xr.to(dt).cuda(), B, n, C, 1e-6, gamma.cuda(), beta.cuda(), None, a, s, mean, None, ws)
+        res[dt] = (a.clone(), s.clone(), mean.clone())
+    for u, v in zip(res[torch.float32], res[bf]):
+        assert torch.equal(u, v)
+    xd = xr.double().reshape(B, n, C)
+    assert err(res[bf][2], xd.mean(1)) < 1e-5
+    # norm-and-cast from bf16 rows
+    a, s = torch.randn(B, C, generator=g), torch.randn(B, C, generator=g)
+    o = torch.empty(B * n, C, device="cuda", dtype=bf)
+    ops.affine_cast(xr.cuda(), B, n, C, a.cuda(), s.cuda(), o)
+    assert err(o.reshape(B, n, C), xd * a.double()[:, None] + s.double()[:, None]) < 5e-2
+    # lean residual class (LDS-DMA GEMM, no activation): bf16 residual rows, plain and affine
+    M, K, N = B * 256, 192, 192
+    A = torch.randn(M, K, generator=g).to(bf)
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf)
+    bias, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g).to(bf)
+    rs, rh = torch.rand(B, N, generator=g) + 0.5, torch.randn(B, N, generator=g)
+    base = A.double() @ Wt.double().T + bias.double()
+    for affine in (False, True):
+        for odt in (torch.float32, bf):
+            out = torch.empty(M, N, device="cuda", dtype=odt)
+            kw = dict(res_scale=rs.cuda(), res_shift=rh.cuda()) if affine else {}
+            ops.conv_gemm(A.cuda(), Wt.cuda(), out, B=B, H=16, W=16, C_=K, N=N, bias=bias.cuda(), res=r.cuda(), **kw)
+            rr = r.double().reshape(B, 256, N)
+            ref = base + ((rr * rs.double()[:, None] + rh.double()[:, None]) if affine else rr).reshape(M, N)
+            assert err(out, ref) < (1e-4 if odt == torch.float32 else 6e-2), (affine, odt)

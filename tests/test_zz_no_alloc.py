@@ -18,12 +18,12 @@ def _run(lib, noalloc, x, B, n, Cc, gamma, beta, ss):
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     if noalloc:
-        rc = lib.uwir_ln2d_affine_noalloc(p(x), x.stride(0), B, n, Cc, 1e-5, p(gamma), p(beta), p(ss), ss.stride(0),
+        rc = lib.uwir_ln2d_affine_noalloc(p(x), 0, x.stride(0), B, n, Cc, 1e-5, p(gamma), p(beta), p(ss), ss.stride(0),
                                           p(a), p(s), p(mean), p(pooled), st)
     else:
         nbytes = int(lib.uwir_ln2d_workspace_bytes(B, n, Cc))
         ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
-        rc = lib.uwir_ln2d_affine(p(x), x.stride(0), B, n, Cc, 1e-5, p(gamma), p(beta), p(ss), ss.stride(0),
+        rc = lib.uwir_ln2d_affine(p(x), 0, x.stride(0), B, n, Cc, 1e-5, p(gamma), p(beta), p(ss), ss.stride(0),
                                   p(a), p(s), p(mean), p(pooled), p(ws), nbytes, st)
     assert rc == 0, lib.uwir_last_error()
     torch.cuda.synchronize()
@@ -57,6 +57,6 @@ def test_noalloc_rejects_shapes_beyond_the_builtin_scratch():
     x = torch.zeros(16, Cc, device="cuda")   # never read: the size check comes first
     v = torch.zeros(B, Cc, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    rc = lib.uwir_ln2d_affine_noalloc(p(x), Cc, B, n, Cc, 1e-5, p(v), p(v), None, 0, p(v), p(v), None, None,
+    rc = lib.uwir_ln2d_affine_noalloc(p(x), 0, Cc, B, n, Cc, 1e-5, p(v), p(v), None, 0, p(v), p(v), None, None,
                                       torch.cuda.current_stream().cuda_stream)
     assert rc == -1 and b"built-in scratch" in lib.uwir_last_error()

@@ -63,13 +63,13 @@ class TeacherArgs(C.Structure):
 _SIGS = {
     "uwir_version": (ci, []),
     "uwir_last_error": (C.c_char_p, []),
-    "uwir_dwt2": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
-    "uwir_idwt2": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "uwir_dwt2": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]),
+    "uwir_idwt2": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "uwir_ln2d_workspace_bytes": (sz, [ci, ci, ci]),
-    "uwir_ln2d_affine": (ci, [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
+    "uwir_ln2d_affine": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "uwir_ln2d_noalloc_max_bytes": (sz, []),
-    "uwir_ln2d_affine_noalloc": (ci, [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
-    "uwir_affine_cast": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp]),
+    "uwir_ln2d_affine_noalloc": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
+    "uwir_affine_cast": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp]),
     "uwir_chan_attn_fold": (ci, [vp, vp, vp, vp, vp, ci, vp]),
     "uwir_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]),
     "uwir_conv_gemm_workspace_bytes": (sz, [C.POINTER(GemmArgs)]),

@@ -27,8 +27,9 @@ __device__ __forceinline__ float haar_tap() {
     return s * s;
 }
 
+template <typename TS>   // sub-band rows: fp32, or bf16 (the student's bf16 sub-band stream)
 __global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, int ldx, int H, int W, int C4, int h,
-                                                   int w, float* __restrict__ ll, int ld_ll, float* __restrict__ hf,
+                                                   int w, TS* __restrict__ ll, int ld_ll, TS* __restrict__ hf,
                                                    int ld_hf, size_t total) {
     const float k = haar_tap();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -51,15 +52,16 @@ __global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, 
 #undef HAAR
         int C = 4 * C4;
         store4(ll + p * ld_ll + 4 * c4, o_ll);
-        float* hp = hf + p * ld_hf + 4 * c4;
+        TS* hp = hf + p * ld_hf + 4 * c4;
         store4(hp, o_lh);
         store4(hp + C, o_hl);
         store4(hp + 2 * C, o_hh);
     }
 }
 
+template <typename TH>   // high-frequency rows: fp32 or bf16
 __global__ void __launch_bounds__(256) idwt2_kernel(const float* __restrict__ ll, int ld_ll,
-                                                    const float* __restrict__ hf, int ld_hf, int h, int w, int C4,
+                                                    const TH* __restrict__ hf, int ld_hf, int h, int w, int C4,
                                                     float* __restrict__ out, int ldo, size_t total) {
     const float k = haar_tap();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -71,7 +73,7 @@ __global__ void __launch_bounds__(256) idwt2_kernel(const float* __restrict__ ll
         int b = (int)(q / h);
         int C = 4 * C4;
         float4 vll = load4(ll + p * ld_ll + 4 * c4);
-        const float* hp = hf + p * ld_hf + 4 * c4;
+        const TH* hp = hf + p * ld_hf + 4 * c4;
         float4 vlh = load4(hp), vhl = load4(hp + C), vhh = load4(hp + 2 * C);
         float4 o00, o01, o10, o11;
 #define IHAAR(F)                                                        \
@@ -98,29 +100,39 @@ static inline int ew_grid(size_t total, int block = 256) {
     return (int)g;
 }
 
-extern "C" int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, float* ll, int ld_ll, float* hf,
-                         int ld_hf, uwir_stream_t stream) {
+extern "C" int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf,
+                         int ld_hf, int sub_dtype, uwir_stream_t stream) {
     UWIR_CHECK(x && ll && hf, "dwt2: null pointer");
+    UWIR_CHECK(sub_dtype == UWIR_F32 || sub_dtype == UWIR_BF16, "dwt2: bad sub-band dtype");
     UWIR_CHECK(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "dwt2: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     UWIR_CHECK(ldx >= C && ld_ll >= C && ld_hf >= 3 * C && ldx % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
                "dwt2: bad strides");
     int h = H / 2, w = W / 2;
     size_t total = (size_t)B * h * w * (C / 4);
-    hipLaunchKernelGGL(dwt2_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4, h, w,
-                       ll, ld_ll, hf, ld_hf, total);
+    if (sub_dtype == UWIR_BF16)
+        hipLaunchKernelGGL(dwt2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4,
+                           h, w, (bf16_t*)ll, ld_ll, (bf16_t*)hf, ld_hf, total);
+    else
+        hipLaunchKernelGGL(dwt2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4,
+                           h, w, (float*)ll, ld_ll, (float*)hf, ld_hf, total);
     UWIR_LAUNCH_CHECK("dwt2");
     return UWIR_OK;
 }
 
-extern "C" int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf, int B, int h, int w, int C,
+extern "C" int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C,
                           float* out, int ldo, uwir_stream_t stream) {
     UWIR_CHECK(ll && hf && out, "idwt2: null pointer");
+    UWIR_CHECK(hf_dtype == UWIR_F32 || hf_dtype == UWIR_BF16, "idwt2: bad hf dtype");
     UWIR_CHECK(B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "idwt2: bad shape");
     UWIR_CHECK(ldo >= C && ld_ll >= C && ld_hf >= 3 * C && ldo % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
                "idwt2: bad strides");
     size_t total = (size_t)B * h * w * (C / 4);
-    hipLaunchKernelGGL(idwt2_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll, hf, ld_hf, h,
-                       w, C / 4, out, ldo, total);
+    if (hf_dtype == UWIR_BF16)
+        hipLaunchKernelGGL(idwt2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll,
+                           (const bf16_t*)hf, ld_hf, h, w, C / 4, out, ldo, total);
+    else
+        hipLaunchKernelGGL(idwt2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll,
+                           (const float*)hf, ld_hf, h, w, C / 4, out, ldo, total);
     UWIR_LAUNCH_CHECK("idwt2");
     return UWIR_OK;
 }
@@ -135,7 +147,8 @@ extern "C" int uwir_idwt2(const float* ll, int ld_ll, const float* hf, int ld_hf
 #define LN_ROWS_PER_BLOCK 128
 #define LN_SLAB_Q 64  // channel quads per block (256 channels)
 
-__global__ void __launch_bounds__(256) ln_partial_kernel(const float* __restrict__ x, int ldx, int n, int C4,
+template <typename TX>
+__global__ void __launch_bounds__(256) ln_partial_kernel(const TX* __restrict__ x, int ldx, int n, int C4,
                                                          double* __restrict__ part, int nchunks) {
     // threads: tx = quad within the slab (0..qs-1), ty = row lane (0..rl-1); rl = 256 / qs uses (nearly) every thread
     // whatever the width (C = 192: 48 quads x 5 row lanes), 4 independent 16-byte loads in flight per thread
@@ -148,7 +161,7 @@ __global__ void __launch_bounds__(256) ln_partial_kernel(const float* __restrict
     float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
     const bool active = ty < rl;
     if (active) {
-        const float* base = x + (size_t)b * n * ldx + 4 * q;
+        const TX* base = x + (size_t)b * n * ldx + 4 * q;
         const float4 K = load4(base);
         const int r0 = chunk * LN_ROWS_PER_BLOCK, r1 = min(n, r0 + LN_ROWS_PER_BLOCK);
 #define LN_ACC(v)                                                                   \
@@ -188,7 +201,8 @@ __global__ void __launch_bounds__(256) ln_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restrict__ x, int ldx, int n, int C,
+template <typename TX>
+__global__ void __launch_bounds__(256) ln_finalize_kernel(const TX* __restrict__ x, int ldx, int n, int C,
                                                           const double* __restrict__ part, int nchunks, float eps,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
@@ -214,7 +228,7 @@ __global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restric
         ss += __shfl_xor(ss, off);
     }
     if (!valid || l != 0) return;
-    double K = (double)x[(size_t)b * n * ldx + c];
+    double K = (double)(float)x[(size_t)b * n * ldx + c];
     double md = s / n;
     double mean = K + md;
     double var = ss / n - md * md;
@@ -240,11 +254,12 @@ extern "C" size_t uwir_ln2d_workspace_bytes(int B, int n, int C) {
     return (size_t)B * nchunks * C * 2 * sizeof(double);
 }
 
-extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+extern "C" int uwir_ln2d_affine(const void* x, int x_dtype, int ldx, int B, int n, int C, float eps, const float* gamma,
                                 const float* beta, const float* scale_shift, int ss_ld, float* a_out, float* s_out,
                                 float* mean_out, float* pooled_out, void* workspace, size_t workspace_bytes,
                                 uwir_stream_t stream) {
     UWIR_CHECK(x && workspace, "ln2d: null pointer");
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "ln2d: bad input dtype");
     UWIR_CHECK(B > 0 && n > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0, "ln2d: bad shape B=%d n=%d C=%d ldx=%d",
                B, n, C, ldx);
     UWIR_CHECK((a_out && s_out && gamma && beta) || (!a_out && !s_out && mean_out), "ln2d: inconsistent outputs");
@@ -254,12 +269,15 @@ extern "C" int uwir_ln2d_affine(const float* x, int ldx, int B, int n, int C, fl
     int nchunks = ceil_div(n, LN_ROWS_PER_BLOCK);
     int C4 = C / 4;
     dim3 grid(nchunks, ceil_div(C4, LN_SLAB_Q), B);
-    hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
-                       nchunks);
-    UWIR_LAUNCH_CHECK("ln_partial");
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(B * C * 16, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, C,
-                       (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out,
-                       pooled_out, B);
+#define LN2D_LAUNCH(TX_)                                                                                                  \
+    hipLaunchKernelGGL(ln_partial_kernel<TX_>, grid, dim3(256), 0, (hipStream_t)stream, (const TX_*)x, ldx, n, C4,        \
+                       (double*)workspace, nchunks);                                                                      \
+    UWIR_LAUNCH_CHECK("ln_partial");                                                                                      \
+    hipLaunchKernelGGL(ln_finalize_kernel<TX_>, dim3(ceil_div(B * C * 16, 256)), dim3(256), 0, (hipStream_t)stream,       \
+                       (const TX_*)x, ldx, n, C, (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld, \
+                       a_out, s_out, mean_out, pooled_out, B);
+    if (x_dtype == UWIR_BF16) { LN2D_LAUNCH(bf16_t) } else { LN2D_LAUNCH(float) }
+#undef LN2D_LAUNCH
     UWIR_LAUNCH_CHECK("ln_finalize");
     return UWIR_OK;
 }
@@ -295,7 +313,7 @@ static int ln2d_scratch_for_current_device(void** out) {
 
 extern "C" size_t uwir_ln2d_noalloc_max_bytes(void) { return UWIR_LN2D_NOALLOC_SCRATCH_BYTES; }
 
-extern "C" int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, int C, float eps, const float* gamma,
+extern "C" int uwir_ln2d_affine_noalloc(const void* x, int x_dtype, int ldx, int B, int n, int C, float eps, const float* gamma,
                                         const float* beta, const float* scale_shift, int ss_ld, float* a_out,
                                         float* s_out, float* mean_out, float* pooled_out, uwir_stream_t stream) {
     UWIR_CHECK(B > 0 && n > 0 && C > 0, "ln2d_noalloc: bad shape B=%d n=%d C=%d", B, n, C);
@@ -307,8 +325,8 @@ extern "C" int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, i
     int rc = ln2d_scratch_for_current_device(&ptr);
     if (rc != UWIR_OK) return rc;
     // every partial that ln_finalize reads is written by ln_partial of THIS call first: nothing needs clearing
-    return uwir_ln2d_affine(x, ldx, B, n, C, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out, pooled_out, ptr,
-                            need, stream);
+    return uwir_ln2d_affine(x, x_dtype, ldx, B, n, C, eps, gamma, beta, scale_shift, ss_ld, a_out, s_out, mean_out, pooled_out,
+                            ptr, need, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -316,8 +334,8 @@ extern "C" int uwir_ln2d_affine_noalloc(const float* x, int ldx, int B, int n, i
 // Used where the consumer GEMM is better fed by the LDS-DMA bf16 path than by normalise-on-load:
 // one extra HBM pass (6 B / element) buys the 16-byte DMA pipeline for the whole GEMM.
 // ------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ void __launch_bounds__(256) affine_cast_kernel(const float* __restrict__ x, int ldx, int n, int C4,
+template <typename TX, typename TO>
+__global__ void __launch_bounds__(256) affine_cast_kernel(const TX* __restrict__ x, int ldx, int n, int C4,
                                                           const float* __restrict__ a, const float* __restrict__ sh,
                                                           TO* __restrict__ out, int ldo, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -331,19 +349,22 @@ __global__ void __launch_bounds__(256) affine_cast_kernel(const float* __restric
     }
 }
 
-extern "C" int uwir_affine_cast(const float* x, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
-                                int out_dtype, int ldo, uwir_stream_t stream) {
+extern "C" int uwir_affine_cast(const void* x, int x_dtype, int ldx, int B, int n, int C, const float* a, const float* s,
+                                void* out, int out_dtype, int ldo, uwir_stream_t stream) {
     UWIR_CHECK(x && a && s && out, "affine_cast: null pointer");
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "affine_cast: bad input dtype");
     UWIR_CHECK(B > 0 && n > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && ldo >= C && ldo % 4 == 0,
                "affine_cast: bad shape");
     UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "affine_cast: bad output dtype");
     size_t total = (size_t)B * n * (C / 4);
-    if (out_dtype == UWIR_F32)
-        hipLaunchKernelGGL(affine_cast_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
-                           C / 4, a, s, (float*)out, ldo, total);
-    else
-        hipLaunchKernelGGL(affine_cast_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,
-                           C / 4, a, s, (bf16_t*)out, ldo, total);
+#define AC_LAUNCH(TX_, TO_)                                                                                             \
+    hipLaunchKernelGGL((affine_cast_kernel<TX_, TO_>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,           \
+                       (const TX_*)x, ldx, n, C / 4, a, s, (TO_*)out, ldo, total)
+    if (x_dtype == UWIR_F32 && out_dtype == UWIR_F32) AC_LAUNCH(float, float);
+    else if (x_dtype == UWIR_F32) AC_LAUNCH(float, bf16_t);
+    else if (out_dtype == UWIR_F32) AC_LAUNCH(bf16_t, float);
+    else AC_LAUNCH(bf16_t, bf16_t);
+#undef AC_LAUNCH
     UWIR_LAUNCH_CHECK("affine_cast");
     return UWIR_OK;
 }
@@ -421,7 +442,7 @@ extern "C" int uwir_groupnorm_affine(const float* x, int ldx, int B, int n, int 
     int nchunks = ceil_div(n, LN_ROWS_PER_BLOCK);
     int C4 = C / 4;
     dim3 grid(nchunks, ceil_div(C4, LN_SLAB_Q), B);
-    hipLaunchKernelGGL(ln_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
+    hipLaunchKernelGGL(ln_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, n, C4, (double*)workspace,
                        nchunks);
     UWIR_LAUNCH_CHECK("gn_partial");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * groups, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, n,

@@ -188,7 +188,6 @@ __device__ __forceinline__ void epi_values(const uwir_gemm_args& g, const f32x4 
 static int epi_class(const uwir_gemm_args& g) {
     if (g.blend_out || g.batch_scale || g.store_mode != 0 || !g.out) return EPI_FULL;
     if (!g.res) return EPI_LEAN;
-    if (g.res_dtype != UWIR_F32) return EPI_FULL;   // (the lean residual class starts the accumulators from fp32 rows)
     // (an affine residual's per-image scale / shift must be one vector per 128-row tile)
     return (g.act == UWIR_ACT_NONE && !g.col_scale && (!g.res_scale || (g.OH * g.OW) % 128 == 0)) ? EPI_RES : EPI_FULL;
 }
@@ -217,8 +216,15 @@ __device__ __forceinline__ void epi_start_issue(const uwir_gemm_args& g, f32x4 (
                     st.rh4[j] = *reinterpret_cast<const f32x4*>(g.res_shift + bo);
                 }
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][j] = *reinterpret_cast<const f32x4*>((const float*)g.res + (size_t)min(m_base + i * 16 + fr, M - 1) * g.ldr + n);
+                for (int i = 0; i < TM; ++i) {
+                    const size_t ro = (size_t)min(m_base + i * 16 + fr, M - 1) * g.ldr + n;
+                    if (g.res_dtype == UWIR_BF16) {              // block-uniform
+                        const float4 t = load4((const bf16_t*)g.res + ro);
+                        acc[i][j] = (f32x4){t.x, t.y, t.z, t.w};
+                    } else {
+                        acc[i][j] = *reinterpret_cast<const f32x4*>((const float*)g.res + ro);
+                    }
+                }
             }
         }
     }

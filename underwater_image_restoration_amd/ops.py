@@ -97,15 +97,17 @@ def _ld(t: torch.Tensor) -> int:
 
 
 def dwt2(x: torch.Tensor, B: int, H: int, W: int, C: int, ll: torch.Tensor, hf: torch.Tensor) -> None:
-    _f32(x, ll, hf)
+    _f32(x)
     lib = _lib.load()
-    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _stream(x)), "dwt2")
+    if _dt(ll) != _dt(hf):
+        raise TypeError("dwt2: ll and hf must share a dtype")
+    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _dt(ll), _stream(x)), "dwt2")
 
 
 def idwt2(ll: torch.Tensor, hf: torch.Tensor, B: int, h: int, w: int, C: int, out: torch.Tensor) -> None:
-    _f32(ll, hf, out)
+    _f32(ll, out)
     lib = _lib.load()
-    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream(ll)), "idwt2")
+    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _dt(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream(ll)), "idwt2")
 
 
 def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
@@ -114,10 +116,10 @@ def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
 
 def ln2d_affine(x: torch.Tensor, B: int, n: int, C_: int, eps: float, gamma, beta, scale_shift, a_out, s_out,
                 mean_out, pooled_out, workspace: torch.Tensor) -> None:
-    _f32(x, gamma, beta, scale_shift, a_out, s_out, mean_out, pooled_out)
+    _f32(gamma, beta, scale_shift, a_out, s_out, mean_out, pooled_out)
     lib = _lib.load()
     ss_ld = 0 if scale_shift is None else _ld(scale_shift)
-    _lib.check(lib.uwir_ln2d_affine(_p(x), _ld(x), B, n, C_, eps, _p(gamma), _p(beta), _p(scale_shift), ss_ld,
+    _lib.check(lib.uwir_ln2d_affine(_p(x), _dt(x), _ld(x), B, n, C_, eps, _p(gamma), _p(beta), _p(scale_shift), ss_ld,
                                     _p(a_out), _p(s_out), _p(mean_out), _p(pooled_out), _p(workspace),
                                     workspace.numel() * workspace.element_size(), _stream(x)), "ln2d_affine")
 
@@ -460,10 +462,10 @@ def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cou
 
 
 def affine_cast(x: torch.Tensor, B: int, n: int, C_: int, a, s, out: torch.Tensor) -> None:
-    """out[m, c] = a[b, c] * x[m, c] + s[b, c] (b = m // n); x fp32, out fp32 / bf16."""
-    _f32(x, a, s)
+    """out[m, c] = a[b, c] * x[m, c] + s[b, c] (b = m // n); x and out fp32 / bf16."""
+    _f32(a, s)
     lib = _lib.load()
-    _lib.check(lib.uwir_affine_cast(_p(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream(x)),
+    _lib.check(lib.uwir_affine_cast(_p(x), _dt(x), _ld(x), B, n, C_, _p(a), _p(s), _p(out), _dt(out), _ld(out), _stream(x)),
                "affine_cast")
 
 

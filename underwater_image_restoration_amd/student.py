@@ -296,7 +296,9 @@ class NAFNetWFIGate(nn.Module):
         tg = f"L{lvl}"
         buf = lambda name, cols, dt=f32, zero=False: self._buf(tg + name, Mr, cols, dt, dev, zero)  # noqa: E731
         small = lambda name, cols: self._buf(tg + name, B, cols, f32, dev)  # noqa: E731
-        ll, hf = buf("ll", Cc), buf("hf", Cw)
+        # bf16 mode: the sub-band stream (ll, hf, x1, the block's hf output) is bf16 -- these rows are read by LayerNorm
+        # statistics, the norm-and-cast pass, residual epilogues and the inverse transform, all HBM-bound; sums stay fp32
+        ll, hf = buf("ll", Cc, adt), buf("hf", Cw, adt)
         ops.dwt2(x_in, B, h2, w2, Cc, ll, hf)
         ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, n, Cw) // 8, 1), torch.float64, dev)
 
@@ -340,7 +342,7 @@ class NAFNetWFIGate(nn.Module):
         att = buf("att", Cw, adt)
         hd = Cw // 12
         ops.flash_attn(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], None, B, n, 12, hd, 0.0, att, None)
-        x1 = buf("x1", Cw)
+        x1 = buf("x1", Cw, adt)
         ops.conv_gemm(att, bp["proj_w"], x1, B=B, H=h, W=w, C_=Cw, N=Cw, bias=bp["proj_b"], res=hf, res_scale=rs, res_shift=rh)
         a2, s2 = small("a2", Cw), small("s2", Cw)
         o, ln_ = bp["norm2_ss"]
