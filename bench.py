@@ -95,13 +95,13 @@ def _op_work(name: str, a: tuple, k: dict):
         return "depthwise 3x3+5x5+7x7", "byte", float(B * H * W * C) * (_esz(x) + 3 * _esz(out))
     if name == "ln2d_affine":
         x, B, n, C = a[0], a[1], a[2], a[3]
-        return "LayerNorm2d statistics", "byte", float(B * n * C) * 4
+        return "LayerNorm2d statistics", "byte", float(B * n * C) * _esz(x)
     if name == "dwt2":
-        B, H, W, C = a[1], a[2], a[3], a[4]
-        return "Haar DWT", "byte", 2.0 * 4 * B * H * W * C
+        x, B, H, W, C, ll = a[0], a[1], a[2], a[3], a[4], a[5]
+        return "Haar DWT", "byte", float(B * H * W * C) * (_esz(x) + _esz(ll))
     if name == "idwt2":
-        B, h, w, C = a[2], a[3], a[4], a[5]
-        return "Haar IDWT", "byte", 2.0 * 4 * B * 4 * h * w * C
+        ll, hf, B, h, w, C, out = a[0], a[1], a[2], a[3], a[4], a[5], a[6]
+        return "Haar IDWT", "byte", float(B * h * w * C) * (_esz(ll) + 3 * _esz(hf) + 4 * _esz(out))
     if name == "fft2_amp_phase":
         B, H, W, C = a[1], a[2], a[3], a[4]
         return "fft2 -> amp, phase", "byte", 3.0 * 4 * B * H * W * C
@@ -110,7 +110,7 @@ def _op_work(name: str, a: tuple, k: dict):
         return "ifft2(amp, phase) + addend", "byte", 4.0 * 4 * B * H * W * C
     if name == "affine_cast":
         x, B, n, C, out = a[0], a[1], a[2], a[3], a[6]
-        return "affine_cast (norm materialised)", "byte", float(B * n * C) * (4 + _esz(out))
+        return "affine_cast (norm materialised)", "byte", float(B * n * C) * (_esz(x) + _esz(out))
     if name in ("sde_posterior_step", "sde_euler_step"):
         return "fused SDE step", "byte", 20.0 * a[0].numel()
     if name == "linear_attention":
@@ -121,11 +121,11 @@ def _op_work(name: str, a: tuple, k: dict):
         x, y = a[0], a[3]
         return "channel LayerNorm rows", "byte", float(x.shape[0] * x.shape[1]) * (4 + _esz(y) + (4 if k.get("res") is not None else 0))
     if name == "head_conv3x3":
-        B, H, W, Cin = a[1], a[2], a[3], a[4]
-        return "final norm + head 3x3 + clamp", "byte", float(B * H * W) * (4 * Cin + 3 * 4 * 2)
+        x, B, H, W, Cin = a[0], a[1], a[2], a[3], a[4]
+        return "final norm + head 3x3 + clamp", "byte", float(B * H * W) * (_esz(x) * Cin + 3 * 4 * 2)
     if name == "stem_conv3x3":
         x, out = a[0], a[3]
-        return "stem 3x3", "byte", float(x.numel() * 4 + out.shape[0] * 64 * 4)
+        return "stem 3x3", "byte", float(x.numel() * 4 + out.shape[0] * 64 * _esz(out))
     return None
 
 

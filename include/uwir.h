@@ -54,13 +54,13 @@ const char* uwir_last_error(void);
  * hf [B,H/2,W/2,3C] = [lh|hl|hh] (stride ld_hf); odd trailing row/column dropped like the
  * reference's stride-2 valid conv.  C % 4 == 0.  ll and hf are written as sub_dtype: fp32, or bf16 (the student's
  * bf16 mode keeps its sub-band stream -- ll, hf and the WTB's residual rows -- in bf16; the Haar sums are fp32). */
-int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf, int ld_hf,
+int uwir_dwt2(const void* x, int x_dtype, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf, int ld_hf,
               int sub_dtype, uwir_stream_t stream);
 
 /* ---- S/dwt_fft.py:42-58 idwt2 ------------------------------------------------------------
- * ll [B,h,w,C] fp32, hf [B,h,w,3C]=[lh|hl|hh] of hf_dtype (fp32 or bf16) -> out [B,2h,2w,C] fp32. */
-int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C, float* out,
-               int ldo, uwir_stream_t stream);
+ * ll [B,h,w,C] fp32, hf [B,h,w,3C]=[lh|hl|hh] of hf_dtype (fp32 or bf16) -> out [B,2h,2w,C] of out_dtype. */
+int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C, void* out,
+               int out_dtype, int ldo, uwir_stream_t stream);
 
 /* ---- S/utils.py:10-36 LayerNorm2d / AdaLayerNorm2d ------------------------------------------
  * Per-(b,c) statistics over the n = H*W rows of x [B,n,C]; emits the folded affine
@@ -215,14 +215,14 @@ int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs, int ws, f
                                uwir_stream_t stream);
 
 /* ---- S/model.py:81,133 stem: Conv2d(Cin,Cout,3,padding=1) reading the NCHW input image -------
- * w repacked [3,3,Cin,Cout]; out NHWC fp32.  Cout % 4 == 0. */
+ * w repacked [3,3,Cin,Cout]; out NHWC rows of out_dtype (bf16 needs Cin <= 4, Cout % 16 == 0).  Cout % 4 == 0. */
 int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout,
-                      float* out, int ldo, uwir_stream_t stream);
+                      void* out, int out_dtype, int ldo, uwir_stream_t stream);
 
 /* ---- S/model.py:158-161 final_norm -> head conv3x3 -> clamp(out + input, 0, 1) ----------------
- * x NHWC fp32 with the final LayerNorm2d folded as a_scale/a_shift [B,Cin]; w repacked
- * [Cout,3,3,Cin]; residual/out NCHW fp32; preclamp (optional) receives out+input before the clamp. */
-int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* a_scale,
+ * x NHWC rows of x_dtype (bf16 needs Cin % 16 == 0) with the final LayerNorm2d folded as a_scale/a_shift [B,Cin]; w
+ * repacked [Cout,3,3,Cin]; residual/out NCHW fp32; preclamp (optional) receives out+input before the clamp. */
+int uwir_head_conv3x3(const void* x, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* a_scale,
                       const float* a_shift, const float* w, const float* bias, int Cout, const float* residual_nchw,
                       float* out_nchw, float* preclamp_nchw, uwir_stream_t stream);
 
@@ -235,10 +235,11 @@ int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, con
  * gather of windows before the network and no stitch copy after it.  `win` is a DEVICE array of nwin descriptors. */
 typedef struct uwir_window { int frame, y, x, cy0, cy1, cx0, cx1, reserved; } uwir_window;
 int uwir_stem_conv3x3_win(const float* frames, int Cin, int FH, int FW, const uwir_window* win, int nwin, int T,
-                          const float* w, const float* bias, int Cout, float* out, int ldo, uwir_stream_t stream);
+                          const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
+                          uwir_stream_t stream);
 int uwir_bilinear_win(const float* frames, int M, int FH, int FW, const uwir_window* win, int nwin, int T, float* dst,
                       int ldd, int hd, int wd, uwir_stream_t stream);
-int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, int Cin, const float* a_scale, const float* a_shift,
+int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nwin, int T, int Cin, const float* a_scale, const float* a_shift,
                           const float* w, const float* bias, int Cout, const float* frames_in, float* frames_out, int FH,
                           int FW, const uwir_window* win, uwir_stream_t stream);
 

@@ -28,7 +28,7 @@ def test_version_and_error_channel_work_without_a_gpu():
     lib = _lib.load()
     assert lib.uwir_version() >= 100
     # argument validation happens before any HIP call, so it is exercisable on a CPU-only box
-    rc = lib.uwir_dwt2(None, 0, 1, 4, 4, 4, None, 0, None, 0, 0, None)
+    rc = lib.uwir_dwt2(None, 0, 0, 1, 4, 4, 4, None, 0, None, 0, 0, None)
     assert rc == -1 and b"dwt2" in lib.uwir_last_error()
 
 

@@ -63,8 +63,8 @@ class TeacherArgs(C.Structure):
 _SIGS = {
     "uwir_version": (ci, []),
     "uwir_last_error": (C.c_char_p, []),
-    "uwir_dwt2": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]),
-    "uwir_idwt2": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "uwir_dwt2": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]),
+    "uwir_idwt2": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
     "uwir_ln2d_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_ln2d_affine": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "uwir_ln2d_noalloc_max_bytes": (sz, []),
@@ -83,11 +83,11 @@ _SIGS = {
     "uwir_fft2_amp_phase": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, sz, vp]),
     "uwir_ifft2_polar_add": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, sz, vp]),
     "uwir_bilinear_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
-    "uwir_stem_conv3x3": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, ci, vp]),
-    "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
-    "uwir_stem_conv3x3_win": (ci, [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
+    "uwir_stem_conv3x3": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "uwir_stem_conv3x3_win": (ci, [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_bilinear_win": (ci, [vp, ci, ci, ci, vp, ci, ci, vp, ci, ci, ci, vp]),
-    "uwir_head_conv3x3_win": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
+    "uwir_head_conv3x3_win": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
     "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_ln_rows": (ci, [vp, ci, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, sz, vp, ci, sz, vp]),

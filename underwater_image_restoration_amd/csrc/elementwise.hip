@@ -27,8 +27,8 @@ __device__ __forceinline__ float haar_tap() {
     return s * s;
 }
 
-template <typename TS>   // sub-band rows: fp32, or bf16 (the student's bf16 sub-band stream)
-__global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, int ldx, int H, int W, int C4, int h,
+template <typename TX, typename TS>   // feature rows in / sub-band rows out: fp32, or bf16 (the student's bf16 mode)
+__global__ void __launch_bounds__(256) dwt2_kernel(const TX* __restrict__ x, int ldx, int H, int W, int C4, int h,
                                                    int w, TS* __restrict__ ll, int ld_ll, TS* __restrict__ hf,
                                                    int ld_hf, size_t total) {
     const float k = haar_tap();
@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, 
         size_t q = p / w;
         int oy = (int)(q % h);
         int b = (int)(q / h);
-        const float* r0 = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * ldx + 4 * c4;
-        const float* r1 = r0 + (size_t)W * ldx;
+        const TX* r0 = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * ldx + 4 * c4;
+        const TX* r1 = r0 + (size_t)W * ldx;
         float4 a = load4(r0), bb = load4(r0 + ldx), c = load4(r1), d = load4(r1 + ldx);
         float4 o_ll, o_lh, o_hl, o_hh;
 #define HAAR(F)                                             \
@@ -59,10 +59,10 @@ __global__ void __launch_bounds__(256) dwt2_kernel(const float* __restrict__ x, 
     }
 }
 
-template <typename TH>   // high-frequency rows: fp32 or bf16
+template <typename TH, typename TO>   // high-frequency rows in / feature rows out: fp32 or bf16
 __global__ void __launch_bounds__(256) idwt2_kernel(const float* __restrict__ ll, int ld_ll,
                                                     const TH* __restrict__ hf, int ld_hf, int h, int w, int C4,
-                                                    float* __restrict__ out, int ldo, size_t total) {
+                                                    TO* __restrict__ out, int ldo, size_t total) {
     const float k = haar_tap();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int c4 = (int)(i % C4);
@@ -84,8 +84,8 @@ __global__ void __launch_bounds__(256) idwt2_kernel(const float* __restrict__ ll
         IHAAR(x) IHAAR(y) IHAAR(z) IHAAR(w)
 #undef IHAAR
         int W2 = 2 * w;
-        float* r0 = out + (((size_t)b * 2 * h + 2 * oy) * W2 + 2 * ox) * ldo + 4 * c4;
-        float* r1 = r0 + (size_t)W2 * ldo;
+        TO* r0 = out + (((size_t)b * 2 * h + 2 * oy) * W2 + 2 * ox) * ldo + 4 * c4;
+        TO* r1 = r0 + (size_t)W2 * ldo;
         store4(r0, o00);
         store4(r0 + ldo, o01);
         store4(r1, o10);
@@ -100,39 +100,43 @@ static inline int ew_grid(size_t total, int block = 256) {
     return (int)g;
 }
 
-extern "C" int uwir_dwt2(const float* x, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf,
+extern "C" int uwir_dwt2(const void* x, int x_dtype, int ldx, int B, int H, int W, int C, void* ll, int ld_ll, void* hf,
                          int ld_hf, int sub_dtype, uwir_stream_t stream) {
     UWIR_CHECK(x && ll && hf, "dwt2: null pointer");
-    UWIR_CHECK(sub_dtype == UWIR_F32 || sub_dtype == UWIR_BF16, "dwt2: bad sub-band dtype");
+    UWIR_CHECK((sub_dtype == UWIR_F32 || sub_dtype == UWIR_BF16) && (x_dtype == UWIR_F32 || x_dtype == UWIR_BF16), "dwt2: bad dtype");
     UWIR_CHECK(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "dwt2: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     UWIR_CHECK(ldx >= C && ld_ll >= C && ld_hf >= 3 * C && ldx % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
                "dwt2: bad strides");
     int h = H / 2, w = W / 2;
     size_t total = (size_t)B * h * w * (C / 4);
-    if (sub_dtype == UWIR_BF16)
-        hipLaunchKernelGGL(dwt2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4,
-                           h, w, (bf16_t*)ll, ld_ll, (bf16_t*)hf, ld_hf, total);
-    else
-        hipLaunchKernelGGL(dwt2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4,
-                           h, w, (float*)ll, ld_ll, (float*)hf, ld_hf, total);
+#define DWT_LAUNCH(TX_, TS_)                                                                                            \
+    hipLaunchKernelGGL((dwt2_kernel<TX_, TS_>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const TX_*)x,   \
+                       ldx, H, W, C / 4, h, w, (TS_*)ll, ld_ll, (TS_*)hf, ld_hf, total)
+    if (x_dtype == UWIR_F32 && sub_dtype == UWIR_F32) DWT_LAUNCH(float, float);
+    else if (x_dtype == UWIR_F32) DWT_LAUNCH(float, bf16_t);
+    else if (sub_dtype == UWIR_F32) DWT_LAUNCH(bf16_t, float);
+    else DWT_LAUNCH(bf16_t, bf16_t);
+#undef DWT_LAUNCH
     UWIR_LAUNCH_CHECK("dwt2");
     return UWIR_OK;
 }
 
 extern "C" int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C,
-                          float* out, int ldo, uwir_stream_t stream) {
+                          void* out, int out_dtype, int ldo, uwir_stream_t stream) {
     UWIR_CHECK(ll && hf && out, "idwt2: null pointer");
-    UWIR_CHECK(hf_dtype == UWIR_F32 || hf_dtype == UWIR_BF16, "idwt2: bad hf dtype");
+    UWIR_CHECK((hf_dtype == UWIR_F32 || hf_dtype == UWIR_BF16) && (out_dtype == UWIR_F32 || out_dtype == UWIR_BF16), "idwt2: bad dtype");
     UWIR_CHECK(B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "idwt2: bad shape");
     UWIR_CHECK(ldo >= C && ld_ll >= C && ld_hf >= 3 * C && ldo % 4 == 0 && ld_ll % 4 == 0 && ld_hf % 4 == 0,
                "idwt2: bad strides");
     size_t total = (size_t)B * h * w * (C / 4);
-    if (hf_dtype == UWIR_BF16)
-        hipLaunchKernelGGL(idwt2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll,
-                           (const bf16_t*)hf, ld_hf, h, w, C / 4, out, ldo, total);
-    else
-        hipLaunchKernelGGL(idwt2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll,
-                           (const float*)hf, ld_hf, h, w, C / 4, out, ldo, total);
+#define IDWT_LAUNCH(TH_, TO_)                                                                                           \
+    hipLaunchKernelGGL((idwt2_kernel<TH_, TO_>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ll, ld_ll,      \
+                       (const TH_*)hf, ld_hf, h, w, C / 4, (TO_*)out, ldo, total)
+    if (hf_dtype == UWIR_F32 && out_dtype == UWIR_F32) IDWT_LAUNCH(float, float);
+    else if (hf_dtype == UWIR_F32) IDWT_LAUNCH(float, bf16_t);
+    else if (out_dtype == UWIR_F32) IDWT_LAUNCH(bf16_t, float);
+    else IDWT_LAUNCH(bf16_t, bf16_t);
+#undef IDWT_LAUNCH
     UWIR_LAUNCH_CHECK("idwt2");
     return UWIR_OK;
 }
@@ -701,9 +705,10 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, 
 // Thread-per-pixel form (Cin <= 4, Cout % 16 == 0): the 9 * Cin inputs of a pixel sit in registers, the weights are
 // block-uniform (scalar loads, SGPR operands), 16 output channels at a time.  The form above spends most of its
 // instructions on 27 scalar + 27 vector loads per 4 outputs (0.9 TB/s on the 268 MB fp32 output of the student stem).
+template <typename TO>
 __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict__ x, int B, int Cin, int H, int W,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                         int Cout, float* __restrict__ out, int ldo,
+                                                         int Cout, TO* __restrict__ out, int ldo,
                                                          const uwir_window* __restrict__ win, int FH, int FW) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (ox >= W || oy >= H) return;
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict
         for (int ci = 0; ci < 4; ++ci)
             in[t * 4 + ci] = (ok && ci < Cin) ? xb[ci * plane + (size_t)iy * rs + ix] : 0.f;
     }
-    float* o = out + (((size_t)b * H + oy) * W + ox) * ldo;
+    TO* o = out + (((size_t)b * H + oy) * W + ox) * ldo;
     for (int c0 = 0; c0 < Cout; c0 += 16) {
         float acc[16];
 #pragma unroll
@@ -740,15 +745,22 @@ __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict
 }
 
 extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
-                                 int Cout, float* out, int ldo, uwir_stream_t stream) {
-    UWIR_CHECK(x_nchw && w && out, "stem: null pointer");
+                                 int Cout, void* outv, int out_dtype, int ldo, uwir_stream_t stream) {
+    UWIR_CHECK(x_nchw && w && outv, "stem: null pointer");
+    UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "stem: bad output dtype");
+    float* out = (float*)outv;
     UWIR_CHECK(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout % 4 == 0 && ldo >= Cout && ldo % 4 == 0, "stem: bad shape");
     if (Cin <= 4 && Cout % 16 == 0 && B <= 65535 && ceil_div(H, 4) <= 65535) {
-        hipLaunchKernelGGL(stem_pixel_kernel, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
-                           x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo, (const uwir_window*)nullptr, 0, 0);
+        if (out_dtype == UWIR_BF16)
+            hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
+                               x_nchw, B, Cin, H, W, w, bias, Cout, (bf16_t*)outv, ldo, (const uwir_window*)nullptr, 0, 0);
+        else
+            hipLaunchKernelGGL(stem_pixel_kernel<float>, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
+                               x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo, (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("stem(pixel)");
         return UWIR_OK;
     }
+    UWIR_CHECK(out_dtype == UWIR_F32, "stem: bf16 rows need Cin <= 4 and Cout %% 16 == 0");
     size_t total = (size_t)B * H * W * (Cout / 4);
     hipLaunchKernelGGL(stem_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, B, Cin, H, W, w,
                        bias, Cout / 4, out, ldo);
@@ -757,13 +769,18 @@ extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int
 }
 
 extern "C" int uwir_stem_conv3x3_win(const float* frames, int Cin, int FH, int FW, const uwir_window* win, int nwin, int T,
-                                     const float* w, const float* bias, int Cout, float* out, int ldo,
+                                     const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
                                      uwir_stream_t stream) {
     UWIR_CHECK(frames && win && w && out, "stem_win: null pointer");
+    UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "stem_win: bad output dtype");
     UWIR_CHECK(nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && ldo >= Cout && ldo % 4 == 0, "stem_win: bad shape");
     UWIR_CHECK(Cin >= 1 && Cin <= 4 && Cout % 16 == 0, "stem_win: needs Cin <= 4 and Cout %% 16 == 0");
-    hipLaunchKernelGGL(stem_pixel_kernel, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream, frames,
-                       nwin, Cin, T, T, w, bias, Cout, out, ldo, win, FH, FW);
+    if (out_dtype == UWIR_BF16)
+        hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream,
+                           frames, nwin, Cin, T, T, w, bias, Cout, (bf16_t*)out, ldo, win, FH, FW);
+    else
+        hipLaunchKernelGGL(stem_pixel_kernel<float>, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream,
+                           frames, nwin, Cin, T, T, w, bias, Cout, (float*)out, ldo, win, FH, FW);
     UWIR_LAUNCH_CHECK("stem_win");
     return UWIR_OK;
 }
@@ -920,22 +937,30 @@ static bool head_tiled_ok(int B, int Ho, int Wo, int Cin) {
     return Cin % HT_CC == 0 && B <= 65535 && ceil_div(Ho, HT_H) <= 65535;
 }
 
-extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, int Cin, const float* a_scale,
+extern "C" int uwir_head_conv3x3(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* a_scale,
                                  const float* a_shift, const float* w, const float* bias, int Cout,
                                  const float* residual_nchw, float* out_nchw, float* preclamp_nchw,
                                  uwir_stream_t stream) {
-    UWIR_CHECK(x && w && out_nchw, "head: null pointer");
+    UWIR_CHECK(xv && w && out_nchw, "head: null pointer");
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "head: bad input dtype");
+    const float* x = (const float*)xv;
     UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
                    ldx % 4 == 0,
                "head: bad shape (Cout<=%d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head: a_scale/a_shift must come together");
     if (head_tiled_ok(B, H, W, Cin)) {
-        hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0, (hipStream_t)stream,
-                           x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, preclamp_nchw, H, W, 1,
-                           (const uwir_window*)nullptr, 0, 0);
+        if (x_dtype == UWIR_BF16)
+            hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0,
+                               (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout,
+                               residual_nchw, out_nchw, preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0);
+        else
+            hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0,
+                               (hipStream_t)stream, x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw,
+                               preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0);
         UWIR_LAUNCH_CHECK("head(tile)");
         return UWIR_OK;
     }
+    UWIR_CHECK(x_dtype == UWIR_F32, "head: bf16 rows need Cin %% 16 == 0");
     size_t npix = (size_t)B * H * W;
     size_t blocks = ceil_div_sz(npix, 4);
     if (blocks > 16384) blocks = 16384;
@@ -945,7 +970,7 @@ extern "C" int uwir_head_conv3x3(const float* x, int ldx, int B, int H, int W, i
     return UWIR_OK;
 }
 
-extern "C" int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, int Cin, const float* a_scale,
+extern "C" int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nwin, int T, int Cin, const float* a_scale,
                                      const float* a_shift, const float* w, const float* bias, int Cout,
                                      const float* frames_in, float* frames_out, int FH, int FW, const uwir_window* win,
                                      uwir_stream_t stream) {
@@ -954,9 +979,15 @@ extern "C" int uwir_head_conv3x3_win(const float* x, int ldx, int nwin, int T, i
                    Cout <= HEAD_MAX_COUT && ldx >= Cin && ldx % 4 == 0,
                "head_win: bad shape (Cin %% 16 == 0, Cout <= %d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head_win: a_scale/a_shift must come together");
-    hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in, frames_out, (float*)nullptr, T, T, 1, win,
-                       FH, FW);
+    UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "head_win: bad input dtype");
+    if (x_dtype == UWIR_BF16)
+        hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0,
+                           (hipStream_t)stream, (const bf16_t*)x, ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in,
+                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW);
+    else
+        hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0,
+                           (hipStream_t)stream, (const float*)x, ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in,
+                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW);
     UWIR_LAUNCH_CHECK("head_win");
     return UWIR_OK;
 }

@@ -97,17 +97,17 @@ def _ld(t: torch.Tensor) -> int:
 
 
 def dwt2(x: torch.Tensor, B: int, H: int, W: int, C: int, ll: torch.Tensor, hf: torch.Tensor) -> None:
-    _f32(x)
     lib = _lib.load()
     if _dt(ll) != _dt(hf):
         raise TypeError("dwt2: ll and hf must share a dtype")
-    _lib.check(lib.uwir_dwt2(_p(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _dt(ll), _stream(x)), "dwt2")
+    _lib.check(lib.uwir_dwt2(_p(x), _dt(x), _ld(x), B, H, W, C, _p(ll), _ld(ll), _p(hf), _ld(hf), _dt(ll), _stream(x)), "dwt2")
 
 
 def idwt2(ll: torch.Tensor, hf: torch.Tensor, B: int, h: int, w: int, C: int, out: torch.Tensor) -> None:
-    _f32(ll, out)
+    _f32(ll)
     lib = _lib.load()
-    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _dt(hf), _ld(hf), B, h, w, C, _p(out), _ld(out), _stream(ll)), "idwt2")
+    _lib.check(lib.uwir_idwt2(_p(ll), _ld(ll), _p(hf), _dt(hf), _ld(hf), B, h, w, C, _p(out), _dt(out), _ld(out), _stream(ll)),
+               "idwt2")
 
 
 def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
@@ -284,30 +284,30 @@ def bilinear_nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, hd: int, wd: int
 
 
 def stem_conv3x3(x_nchw: torch.Tensor, w, bias, out: torch.Tensor) -> None:
-    _f32(x_nchw, w, bias, out)
+    _f32(x_nchw, w, bias)
     lib = _lib.load()
     B, Cin, H, W = x_nchw.shape
     Cout = w.shape[-1]
-    _lib.check(lib.uwir_stem_conv3x3(_p(x_nchw), B, Cin, H, W, _p(w), _p(bias), Cout, _p(out), _ld(out), _stream(x_nchw)),
+    _lib.check(lib.uwir_stem_conv3x3(_p(x_nchw), B, Cin, H, W, _p(w), _p(bias), Cout, _p(out), _dt(out), _ld(out), _stream(x_nchw)),
                "stem_conv3x3")
 
 
 def head_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, a_scale, a_shift, w, bias, Cout: int,
                  residual_nchw, out_nchw, preclamp_nchw=None) -> None:
-    _f32(x, a_scale, a_shift, w, bias, residual_nchw, out_nchw, preclamp_nchw)
+    _f32(a_scale, a_shift, w, bias, residual_nchw, out_nchw, preclamp_nchw)
     lib = _lib.load()
-    _lib.check(lib.uwir_head_conv3x3(_p(x), _ld(x), B, H, W, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias), Cout,
+    _lib.check(lib.uwir_head_conv3x3(_p(x), _dt(x), _ld(x), B, H, W, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias), Cout,
                                      _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream(x)), "head_conv3x3")
 
 
 def stem_conv3x3_win(frames: torch.Tensor, win: torch.Tensor, T: int, w, bias, out: torch.Tensor) -> None:
     """Stem conv over the T x T windows `win` (int32 [nwin, 8] device descriptors, see uwir_window) of NCHW frames."""
-    _f32(frames, w, bias, out)
+    _f32(frames, w, bias)
     if frames.dim() != 4 or not frames.is_contiguous() or win.dtype != torch.int32 or not win.is_contiguous() or win.shape[1] != 8:
         raise ValueError("stem_conv3x3_win: frames must be contiguous NCHW, win an int32 [nwin, 8] tensor")
     _, Cin, FH, FW = frames.shape
     _lib.check(_lib.load().uwir_stem_conv3x3_win(_p(frames), Cin, FH, FW, _p(win), win.shape[0], T, _p(w), _p(bias), w.shape[-1],
-                                                 _p(out), _ld(out), _stream(frames)), "stem_conv3x3_win")
+                                                 _p(out), _dt(out), _ld(out), _stream(frames)), "stem_conv3x3_win")
 
 
 def bilinear_win(frames: torch.Tensor, win: torch.Tensor, T: int, dst: torch.Tensor, hd: int, wd: int) -> None:
@@ -321,11 +321,11 @@ def bilinear_win(frames: torch.Tensor, win: torch.Tensor, T: int, dst: torch.Ten
 
 def head_conv3x3_win(x: torch.Tensor, T: int, Cin: int, a_scale, a_shift, w, bias, Cout: int, frames_in: torch.Tensor,
                      frames_out: torch.Tensor, win: torch.Tensor) -> None:
-    _f32(x, a_scale, a_shift, w, bias, frames_in, frames_out)
+    _f32(a_scale, a_shift, w, bias, frames_in, frames_out)
     if frames_in.shape != frames_out.shape or not frames_in.is_contiguous() or not frames_out.is_contiguous():
         raise ValueError("head_conv3x3_win: frames must be contiguous NCHW tensors of one shape")
     _, _, FH, FW = frames_in.shape
-    _lib.check(_lib.load().uwir_head_conv3x3_win(_p(x), _ld(x), win.shape[0], T, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias),
+    _lib.check(_lib.load().uwir_head_conv3x3_win(_p(x), _dt(x), _ld(x), win.shape[0], T, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias),
                                                  Cout, _p(frames_in), _p(frames_out), FH, FW, _p(win), _stream(x)),
                "head_conv3x3_win")
 

@@ -386,7 +386,7 @@ class NAFNetWFIGate(nn.Module):
             nchw = lambda t, c: t[:, :c].reshape(B, h, w, c).permute(0, 3, 1, 2).float().clone()  # noqa: E731
             taps.update(hf=nchw(hf_out, Cw), lf=nchw(lf, Cc), t_out=nchw(gate_in, Cc),
                         f_out=nchw(gate_in[:, Cc:], Cc), merged=nchw(merged, Cc), alpha=alpha.permute(0, 3, 1, 2),
-                        out=out[:, :Cc].reshape(B, h2, w2, Cc).permute(0, 3, 1, 2).clone(),
+                        out=out[:, :Cc].reshape(B, h2, w2, Cc).permute(0, 3, 1, 2).float().clone(),
                         wtb=dict(qkv_base=nchw(qkv_base, 3 * Cw), att=nchw(att, Cw),
                                  x1=nchw(x1, Cw)),
                         sffb=dict(spatial=nchw(spatial, Cc), freq=None))
@@ -449,15 +449,16 @@ class NAFNetWFIGate(nn.Module):
             elif masks is not None:
                 ops.bilinear_nchw_to_nhwc(masks, gi[:, 2 * ch[lvl]:2 * ch[lvl] + Mk], h, w)
             gate_in.append(gi)
-            feat.append([self._buf(f"feat{lvl}_{i}", B * Hl * Wl, ch[lvl], f32, dev) for i in range(2)])
-            cat.append(self._buf(f"cat{lvl}", B * Hl * Wl, 2 * ch[lvl], f32, dev) if lvl < L - 1 else None)
+            # (bf16 mode: the feature stream between blocks, the skip concats and the sub-bands are bf16 rows)
+            feat.append([self._buf(f"feat{lvl}_{i}", B * Hl * Wl, ch[lvl], pk["adt"], dev) for i in range(2)])
+            cat.append(self._buf(f"cat{lvl}", B * Hl * Wl, 2 * ch[lvl], pk["adt"], dev) if lvl < L - 1 else None)
 
         if win is not None:
             ops.stem_conv3x3_win(x, win, H, pk["stem_w"], pk["stem_b"], feat[0][0])
         else:
             ops.stem_conv3x3(x, pk["stem_w"], pk["stem_b"], feat[0][0])
         if taps is not None:
-            taps["stem"] = feat[0][0].reshape(B, H, W, ch[0]).permute(0, 3, 1, 2).clone()
+            taps["stem"] = feat[0][0].reshape(B, H, W, ch[0]).permute(0, 3, 1, 2).float().clone()
         alphas: List[torch.Tensor] = []
 
         def run_stage(prefix: str, lvl: int, cur: torch.Tensor, final_out: Optional[torch.Tensor]) -> torch.Tensor:
