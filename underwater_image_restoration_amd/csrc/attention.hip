@@ -864,8 +864,10 @@ static inline void probe_mark(int which, hipStream_t stream) {
     }
 }
 
-static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel), bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V
+static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block)
 extern "C" void uwir_attn_variant(int lsv) { g_attn_lsv = lsv; }
+static inline bool attn_lsv_forced() { return g_attn_lsv >= 0 && !(g_attn_lsv & 8); }
+static inline unsigned attn_cap_lds() { return (g_attn_lsv >= 0 && (g_attn_lsv & 16)) ? 56u * 1024u : 0u; }
 
 template <int HD, int NV, int QG, int PF>
 static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_t stream) {
@@ -887,14 +889,15 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
     probe_mark(0, stream);
     // measured (tools/bench_attn.py lsv): hd16 2V 2.18 / 2.02 / 1.83 ms for forms 0 / 1 / 2, hd32 1V 0.53 / 0.51 / 0.47,
     // hd32 2V 0.258 / 0.223 / 0.234
-    const int lsv = P::SUMROW ? 0 : (g_attn_lsv < 0 ? ((HD == 32 && NV == 2) ? 1 : 2) : (g_attn_lsv & 3));
+    const int lsv = P::SUMROW ? 0 : (!attn_lsv_forced() ? ((HD == 32 && NV == 2) ? 1 : 2) : (g_attn_lsv & 3));
+    const unsigned cap = attn_cap_lds();
     const dim3 grid((unsigned)nb);
     if (lsv == 2)
-        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 2>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 2>), grid, dim3(256), cap, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     else if (lsv == 1)
-        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 1>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, P::SUMROW ? 0 : 1>), grid, dim3(256), cap, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     else
-        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, 0>), grid, dim3(256), 0, stream, p, Kp, Vtp, npad, nqb, (int)nb);
+        hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, 0>), grid, dim3(256), cap, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     probe_mark(1, stream);
     // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
     hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, 2, 2>), dim3(ceil_div(n, 256), p.heads, B), dim3(256), 0, stream, p);
