@@ -52,7 +52,7 @@ for name, a, k, ms in rows:
         res = k.get("res")
         if res is not None:
             by += M * N * res.element_size()
-        extra = ",".join(f"{kk}" for kk in ("a_scale", "res", "bias_b", "col_scale", "gate") if k.get(kk) is not None)
+        extra = ",".join(f"{kk}" for kk in ("a_scale", "bias", "batch_bias", "res", "res_scale", "col_scale", "batch_scale", "blend_out") if k.get(kk) is not None)
         key = (f"conv_gemm M{M} N{N} K{K} k{KH} s{st} A:{str(A.dtype)[6:]} out:{'-' if out is None else str(out.dtype)[6:]} "
                f"act{k.get('act', 0)} sm{k.get('store_mode', 0)} [{extra}]")
     else:

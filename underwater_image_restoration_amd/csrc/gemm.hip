@@ -255,6 +255,49 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
     const int N = g.N;
     const int OHW = g.OH * g.OW;
     const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
+    if constexpr (EPI != EPI_FULL) {
+        // Fast path of the lean classes (block-uniform test): bf16 rows in the plain layout, no per-sample bias.  The general
+        // loop below spends ~700 VALU instructions per wave and tile on row / image index arithmetic, edge handling and
+        // layout dispatch -- as much issue time as the 96 MFMAs of a K = 192 tile; here a tile's stores cost ~150.
+        // Same operations in the same order on every value, so results are bit-identical to the general loop.
+        if (g.out && g.out_dtype == UWIR_BF16 && g.store_mode == 0 && N % 8 == 0 && g.ldo % 8 == 0 &&
+            ((uintptr_t)g.out & 15) == 0 && !g.batch_bias) {
+            const int nq = n_base + fq * 16;
+            bf16_t* const obase = (bf16_t*)g.out + nq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16_t* orow = obase + (size_t)(mrow[i] + fr) * g.ldo;
+                const bool row_ok = fr < mcnt[i];
+#pragma unroll
+                for (int jp = 0; jp < TN; jp += 2) {
+                    f32x4 v[2] = {acc[i][jp], acc[i][jp + 1]};
+#define UWIR_EPI_ACT(EXPR)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float x = v[j][e]; v[j][e] = (EXPR); }
+                    switch (g.act) {
+                        case UWIR_ACT_RELU: UWIR_EPI_ACT(x > 0.f ? x : 0.f) break;
+                        case UWIR_ACT_GELU: UWIR_EPI_ACT(act_apply(x, UWIR_ACT_GELU)) break;
+                        case UWIR_ACT_SIGMOID: UWIR_EPI_ACT(sigmoid_fast(x)) break;
+                        case UWIR_ACT_SILU: UWIR_EPI_ACT(x * sigmoid_fast(x)) break;
+                        default: break;
+                    }
+#undef UWIR_EPI_ACT
+                    const bool col_ok = nq + jp * 4 < N;   // N % 8 == 0: the pair of quads is whole or absent
+                    if (g.col_scale && col_ok) {
+                        v[0] *= *reinterpret_cast<const f32x4*>(g.col_scale + nq + jp * 4);
+                        v[1] *= *reinterpret_cast<const f32x4*>(g.col_scale + nq + jp * 4 + 4);
+                    }
+                    if (row_ok && col_ok) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[0][e]; o[4 + e] = (bf16_t)v[1][e]; }
+                        *reinterpret_cast<bf16x8*>(orow + jp * 4) = o;
+                    }
+                }
+            }
+            return;
+        }
+    }
     EpiCols<TN> cols;
     if (EPI == EPI_FULL) epi_cols<TN>(g, n_base, fq, cols);
 #pragma unroll
