@@ -256,21 +256,27 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
     const int OHW = g.OH * g.OW;
     const int Cout4 = N / 4;  // depth-to-space: channels per sub-pixel
     if constexpr (EPI != EPI_FULL) {
-        // Fast path of the lean classes (block-uniform test): bf16 rows in the plain layout, no per-sample bias.  The general
+        // Fast path of the lean classes (block-uniform test): rows in the plain layout, 8-channel groups whole.  The general
         // loop below spends ~700 VALU instructions per wave and tile on row / image index arithmetic, edge handling and
         // layout dispatch -- as much issue time as the 96 MFMAs of a K = 192 tile; here a tile's stores cost ~150.
         // Same operations in the same order on every value, so results are bit-identical to the general loop.
-        if (g.out && g.out_dtype == UWIR_BF16 && g.store_mode == 0 && N % 8 == 0 && g.ldo % 8 == 0 &&
-            ((uintptr_t)g.out & 15) == 0 && !g.batch_bias) {
+        const bool o16 = g.out_dtype == UWIR_BF16;
+        if (g.out && g.store_mode == 0 && N % 8 == 0 && g.ldo % 8 == 0 && ((uintptr_t)g.out & 15) == 0) {
             const int nq = n_base + fq * 16;
-            bf16_t* const obase = (bf16_t*)g.out + nq;
+            const int bld = g.batch_ld ? g.batch_ld : N;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                bf16_t* orow = obase + (size_t)(mrow[i] + fr) * g.ldo;
+                const size_t orow = (size_t)(mrow[i] + fr) * g.ldo + nq;
                 const bool row_ok = fr < mcnt[i];
+                // (per-sample bias: the image of THIS lane's row; lanes past the tile's rows read image 0 and store nothing)
+                const float* bb = g.batch_bias ? g.batch_bias + (size_t)((row_ok ? mrow[i] + fr : 0) / OHW) * bld + nq : nullptr;
 #pragma unroll
                 for (int jp = 0; jp < TN; jp += 2) {
                     f32x4 v[2] = {acc[i][jp], acc[i][jp + 1]};
+                    if (g.batch_bias && nq + jp * 4 < N) {
+                        v[0] += *reinterpret_cast<const f32x4*>(bb + jp * 4);
+                        v[1] += *reinterpret_cast<const f32x4*>(bb + jp * 4 + 4);
+                    }
 #define UWIR_EPI_ACT(EXPR)                                                 \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                          \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float x = v[j][e]; v[j][e] = (EXPR); }
@@ -288,10 +294,15 @@ __device__ __forceinline__ void gemm_epilogue(const uwir_gemm_args& g, const f32
                         v[1] *= *reinterpret_cast<const f32x4*>(g.col_scale + nq + jp * 4 + 4);
                     }
                     if (row_ok && col_ok) {
-                        bf16x8 o;
+                        if (o16) {
+                            bf16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[0][e]; o[4 + e] = (bf16_t)v[1][e]; }
-                        *reinterpret_cast<bf16x8*>(orow + jp * 4) = o;
+                            for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[0][e]; o[4 + e] = (bf16_t)v[1][e]; }
+                            *reinterpret_cast<bf16x8*>((bf16_t*)g.out + orow + jp * 4) = o;
+                        } else {
+                            *reinterpret_cast<f32x4*>((float*)g.out + orow + jp * 4) = v[0];
+                            *reinterpret_cast<f32x4*>((float*)g.out + orow + jp * 4 + 4) = v[1];
+                        }
                     }
                 }
             }
