@@ -185,8 +185,10 @@ int uwir_dwconv_ms(const void* x, int x_dtype, int ldx, int B, int H, int W, int
  * shift is dropped and no running max / rescale is computed; blocks with a larger bound run the online-max loop.
  * With >= uwir_flash_attn_packed_workspace_bytes(B, n, heads, hd, nv) bytes, 256-byte aligned, long bf16 sequences with
  * hd 16 or 32 (n >= 1024, at least 256 query blocks) take the packed-stream kernels: the pre-pass also rewrites K and
- * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier.  The
- * results are the same function of the inputs to bf16 rounding; shapes outside that range return the small size. */
+ * V^T into MFMA-fragment order inside the workspace and the main kernel streams them with no LDS and no barrier; its
+ * pre-pass also stores the per-dimension extremes of the keys, and the bound in use there is the smaller of ub and
+ * max(sum_d max(c q_d kmax_d, c q_d kmin_d), -sum_d min(...)) (every k_d lies in [kmin_d, kmax_d]).  The results are the
+ * same function of the inputs to bf16 rounding; shapes outside that range return the small size. */
 /* Measurement hook with no counterpart in the reference: arms two hipEvent_t for the NEXT uwir_flash_attn call of the
  * calling thread; they are recorded on that call's stream right before / after the launch of its main kernel only
  * (not the pre-pass, not the fallback launch), so a benchmark can time the dominant kernel in place. */

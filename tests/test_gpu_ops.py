@@ -761,6 +761,55 @@ def test_flash_attn_packed_stream(ops, cfg):
         assert err(o_p[n:], refs[0][n:]) < 3e-2
 
 
+@pytest.mark.parametrize("cfg", [(2, 4096 + 7, 8, 16, 2), (1, 2048 + 19, 32, 32, 1)])
+def test_flash_attn_per_dimension_bound(ops, cfg):
+    """Packed-stream attention: a few keys with a large component in a dimension the queries do not use push the
+    Cauchy-Schwarz bound |c q| max|k| far above 90 while every score stays small.  The per-dimension bound (k_d in
+    [kmin_d, kmax_d], extremes from the pack pre-pass; keys padded to 32 count as zeros) keeps those queries on the
+    no-shift stream kernel; queries that DO use the dimension still fall back.  One dimension holds positive keys only."""
+    from underwater_image_restoration_amd import _lib
+    lib = _lib.load()
+    b, n, heads, hd, nv = cfg
+    assert lib.uwir_flash_attn_packed_workspace_bytes(b, n, heads, hd, nv) > lib.uwir_flash_attn_workspace_bytes(b, n, heads) + n * heads * hd  # the packed path is on
+    g = torch.Generator().manual_seed(31)
+    wdt = heads * hd
+    c = 1.4426950408889634 / math.sqrt(hd)
+    q = torch.randn(b * n, heads, hd, generator=g)
+    k = torch.randn(b * n, heads, hd, generator=g)
+    k[:, :, 1] = k[:, :, 1].abs() + 1.0                     # kmin_1 > 0 among the real keys
+    q[:, :, 0] = 0.0
+    out_rows = torch.randperm(b * n, generator=g)[:24]
+    k[out_rows, :, 0] = 300.0                               # outlier keys, positive only: kmin_0 stays near -4
+    hot = torch.arange(0, 256)                              # the first 256 queries of batch 0 use dimension 0: fallback
+    q[hot, :, 0] = 6.0
+    q, k = q.reshape(b * n, wdt).bfloat16().cuda(), k.reshape(b * n, wdt).bfloat16().cuda()
+    v = torch.randn(b * n, wdt, generator=g).bfloat16().cuda()
+    v2 = torch.randn(b * n, wdt, generator=g).bfloat16().cuda() if nv == 2 else None
+    vs = [v] + ([v2] if nv == 2 else [])
+    qn = q.float().reshape(b * n, heads, hd).norm(dim=-1) * c
+    assert float(qn.min()) * 300.0 > 90.0                   # the norm bound rejects every query
+    refs = _attn_ref_cuda(q, k, vs, b, n, heads, hd)
+    outs = {}
+    for variant in (8, 40, "online"):                       # 8: default forms; 40: norm bound alone
+        if variant != "online":
+            lib.uwir_attn_variant(variant)
+        try:
+            o = [torch.empty(b * n, wdt, device="cuda") for _ in range(nv)]
+            ops.flash_attn(q, k, v, v2, b, n, heads, hd, 1.0 / math.sqrt(hd), o[0], o[1] if nv == 2 else None,
+                           fast=variant != "online")
+            torch.cuda.synchronize()
+        finally:
+            lib.uwir_attn_variant(-1)
+        outs[variant] = o
+        for got, ref in zip(o, refs):
+            assert bool(torch.isfinite(got).all())
+            assert err(got, ref) < 3e-2, variant
+    for t, w, o in zip(outs[8], outs[40], outs["online"]):
+        assert torch.equal(w, o)                            # norm bound alone: everything fell back to the online-max loop
+        assert torch.equal(t[:256], o[:256])                # the hot queries still do
+        assert not torch.equal(t[256:], o[256:])            # the rest ran the stream kernel
+
+
 def test_flash_attn_bound_band_60_to_90(ops):
     """The no-shift fast path is taken while the a-priori score bound ub = |c q| max|k| is <= 90 (log2 units).  Drive the
     (60, 90] band on the packed-stream kernel at n = 65536: every query has ub ~ 85 and keys aligned with / against the

@@ -1,0 +1,52 @@
+"""Candidates for a tighter a-priori score bound of the bf16 two-V attention fast path, on the calls of one student forward:
+per sampled query (every 64th) the bound in use |c q| max_k|k|, the per-dimension signed bound
+sum_d max(c q_d kmax_d, c q_d kmin_d) (and its mirror for the minimum), and the true max |score|.
+    python tools/exp/attn_bound_tight.py [size] [batch]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from underwater_image_restoration_amd import ops  # noqa: E402
+from underwater_image_restoration_amd.student import NAFNetWFIGate  # noqa: E402
+from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+MK = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
+model = NAFNetWFIGate(**MK, precision="bf16")
+model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=0))
+model = model.cuda().eval()
+model.overlap_branches = False
+x, z, m = synth_student_inputs(B, S, S, 512, 10, mask_hw=(7, 7), seed=99)
+orig = ops.flash_attn
+
+
+def spy(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=True):
+    if n >= 4096 and v2 is not None:
+        c = (scale if scale else 1.0) * 1.4426950408889634
+        qf = q.float().reshape(B_, n, -1)[:, :, :heads * hd].reshape(B_, n, heads, hd)[:, ::64] * c   # [B, ns, H, D]
+        kf = k.float().reshape(B_, n, -1)[:, :, :heads * hd].reshape(B_, n, heads, hd)
+        kn = kf.norm(dim=-1).amax(dim=1)                       # [B, H]
+        ub0 = qf.norm(dim=-1) * kn[:, None, :]                  # [B, ns, H]
+        kmax, kmin = kf.amax(dim=1), kf.amin(dim=1)             # [B, H, D]
+        hi = torch.maximum(qf * kmax[:, None], qf * kmin[:, None]).sum(-1)
+        lo = torch.minimum(qf * kmax[:, None], qf * kmin[:, None]).sum(-1)
+        ub1 = torch.maximum(hi, -lo)
+        ub1 = torch.minimum(ub1, ub0)
+        tmax = torch.zeros_like(ub0)
+        for b in range(B_):
+            for h in range(heads):
+                s = qf[b, :, h] @ kf[b, :, h].T                 # [ns, n]
+                tmax[b, :, h] = s.abs().amax(dim=1)
+        f = lambda t: f"max {t.max().item():6.1f} p99 {t.flatten().quantile(0.99).item():6.1f} median {t.median().item():6.1f} over90 {100 * (t > 90).float().mean().item():5.1f}%"
+        print(f"n={n} heads={heads} hd={hd}: in use [{f(ub0)}] | per-dim signed [{f(ub1)}] | true max|s| [{f(tmax)}]", flush=True)
+    return orig(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=fast)
+
+
+import underwater_image_restoration_amd.student as st  # noqa: E402
+st.ops.flash_attn = spy
+with torch.no_grad():
+    model(x.cuda(), z.cuda(), m.cuda())
+torch.cuda.synchronize()

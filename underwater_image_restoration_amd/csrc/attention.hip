@@ -20,6 +20,8 @@ struct AttnP {
     int n, heads, hd, out_dtype;
     float c;  // scale * log2(e); 1 when q is pre-scaled
     const float* kmax2;  // optional [B*heads]: max over keys of |k|^2 (bf16 fast path: a-priori score bound)
+    int norm_bound_only;   // tools/: uwir_attn_variant bit 5 -- the Cauchy-Schwarz bound alone decides
+    const unsigned* kext;  // packed path: [B*heads][2][32] order-preserving keys of max_k k_d and max_k (-k_d)
     int* flags;          // split launch: per-block "bound too large, redo with the online-max kernel" marks
 };
 
@@ -519,13 +521,22 @@ template <int HD, int NV> struct PackCfg {
 
 __host__ __device__ static inline size_t pk_align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// order-preserving map float -> unsigned (an integer atomicMax on a zeroed word then is a float max) and back
+__device__ __forceinline__ unsigned attn_okey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float attn_okey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 #define PK_TILES 4   // 256-key tiles per block of the pack pre-pass (the next tile's loads fly during the current gather)
 
 template <int HD, int NV>
 __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ v1,
                                                         int ldv1, const bf16_t* __restrict__ v2, int ldv2, int n, int npad,
                                                         int heads, bf16_t* __restrict__ Kp, bf16_t* __restrict__ Vtp,
-                                                        unsigned* __restrict__ kmax2) {
+                                                        unsigned* __restrict__ kmax2, unsigned* __restrict__ kext) {
     using P = PackCfg<HD, NV>;
     constexpr int DV = P::DV, ROWS = P::ROWS, SV = DV + 8;  // LDS row stride (elements): rows stay 16-byte aligned
     constexpr int PPK = HD / 8;                             // 16-byte pieces per key row
@@ -534,6 +545,11 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int bh = b * heads + head;
     float m = 0.f;
+    // per-dimension extremes of this thread's 8 dimensions (its piece of a key row is the same in every item: 256 % PPK
+    // == 0); keys in [n, npad) count as the zeros they are packed as
+    float dmax[8], dmin[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dmax[e] = -3.0e38f; dmin[e] = 3.0e38f; }
     bf16x8 kv[NIT], vv[NIT][NV];
     // 16-byte pieces, adjacent lanes = adjacent pieces of one key row
     auto load_tile = [&](int k0) {
@@ -565,7 +581,11 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
             const int kl = idx / PPK, piece = idx % PPK, key = k0 + kl;
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float f = (float)kv[it][e]; s = fmaf(f, f, s); }
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)kv[it][e];
+                s = fmaf(f, f, s);
+                if (key < npad) { dmax[e] = fmaxf(dmax[e], f); dmin[e] = fminf(dmin[e], f); }
+            }
 #pragma unroll
             for (int off = 1; off < PPK; off <<= 1) s += __shfl_xor(s, off);   // the PPK lanes of one key
             m = fmaxf(m, s);
@@ -599,6 +619,23 @@ __global__ void __launch_bounds__(256) attn_pack_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if ((tid & 63) == 0 && m > 0.f) atomicMax(kmax2 + bh, __float_as_uint(m));
+    // lanes with the same piece (tid % PPK) hold the same dimensions
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int off = PPK; off < 64; off <<= 1) {
+            dmax[e] = fmaxf(dmax[e], __shfl_xor(dmax[e], off));
+            dmin[e] = fminf(dmin[e], __shfl_xor(dmin[e], off));
+        }
+    }
+    if ((tid & 63) < PPK && dmax[0] >= dmin[0]) {   // (a block wholly past npad saw no key)
+        const int d0 = (tid & 63) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicMax(kext + (size_t)bh * 64 + d0 + e, attn_okey(dmax[e]));
+            atomicMax(kext + (size_t)bh * 64 + 32 + d0 + e, attn_okey(-dmin[e]));
+        }
+    }
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -633,15 +670,31 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
     const float c = p.c;
 
     // ---- Q fragments (pre-multiplied by c: scores come out of the MFMA in the log2 domain) and the score bound
+    // Two a-priori bounds on |score| of a query against EVERY key of its (b, head), the smaller one decides:
+    //   |c q| max_k |k|                                               (Cauchy-Schwarz)
+    //   max(sum_d max(t_d kmax_d, t_d kmin_d), -sum_d min(...))       (per dimension: k_d lies in [kmin_d, kmax_d])
+    // The second is the tight one when a few keys carry a large norm in a direction the query does not share: on the
+    // CFC attentions of the 512 x 512 student it lowers the share of queries above 90 from 36 - 73 % to 0.2 - 2 %
+    // (tools/exp/attn_bound_tight.py).
     bf16x8 qf[QG][KS];
     bool ok = true;
     const float km2 = p.kmax2[bh];
+    float kdmax[KS][8], kdmin[KS][8];   // this lane's dimensions: 16 ks + 8 lh + 0..7
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const unsigned* ke = p.kext + (size_t)bh * 64 + 16 * ks + 8 * lh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kdmax[ks][e] = attn_okey_inv(ke[e]);
+            kdmin[ks][e] = -attn_okey_inv(ke[32 + e]);
+        }
+    }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int q_idx = qbase + 32 * g;
         const bool qok = q_idx < n;
         const bf16_t* qrow = (const bf16_t*)p.q + (size_t)head * HD + (row0 + (qok ? q_idx : 0)) * p.ldq;
-        float q2 = 0.f;
+        float q2 = 0.f, hi = 0.f, lo = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 f;
@@ -652,15 +705,24 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
                 for (int e = 0; e < 4; ++e) {
                     bf16_t t = qok ? (c == 1.f ? v[e] : (bf16_t)((float)v[e] * c)) : (bf16_t)0.f;
                     f[4 * half + e] = t;
-                    q2 = fmaf((float)t, (float)t, q2);
+                    const float tf = (float)t;
+                    q2 = fmaf(tf, tf, q2);
+                    const float a = tf * kdmax[ks][4 * half + e], b2 = tf * kdmin[ks][4 * half + e];
+                    hi += fmaxf(a, b2);
+                    lo += fminf(a, b2);
                 }
             }
             qf[g][ks] = f;
         }
-        unsigned u = __float_as_uint(q2);
-        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        // the other half-wave holds the other 8 dimensions of every 16 of the same query
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2), __float_as_uint(q2), false, false);
         q2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        ok = ok && (sqrtf(q2 * km2) * 1.002f + 1e-3f <= 90.f);
+        auto sh = __builtin_amdgcn_permlane32_swap(__float_as_uint(hi), __float_as_uint(hi), false, false);
+        hi = __uint_as_float(sh[0]) + __uint_as_float(sh[1]);
+        auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(lo), false, false);
+        lo = __uint_as_float(sl[0]) + __uint_as_float(sl[1]);
+        const float ub = p.norm_bound_only ? sqrtf(q2 * km2) : fminf(sqrtf(q2 * km2), fmaxf(hi, -lo));
+        ok = ok && (ub * 1.002f + 1e-3f <= 90.f);
     }
     // wave-uniform (the kernel has no barrier): a wave whose 32 * QG queries do not all pass marks their 128-query
     // group(s) for the online-max launch and leaves; the other waves of the block carry on
@@ -833,9 +895,10 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
     }
 }
 
-// workspace: [B*heads] max|k|^2, one int per 256-query block, then (packed path) Kp and Vtp, 256-byte aligned
+// workspace: [B*heads] max|k|^2, one int per 128-query group, [B*heads][2][32] per-dimension key extremes (packed path),
+// then (packed path) Kp and Vtp, 256-byte aligned
 static size_t attn_hdr_bytes(int B, int n, int heads) {
-    return ((size_t)B * heads + (size_t)ceil_div(n, 128) * heads * B) * sizeof(float);
+    return ((size_t)B * heads + (size_t)ceil_div(n, 128) * heads * B + (size_t)B * heads * 64) * sizeof(float);
 }
 static bool attn_packed_shape(int B, int n, int heads, int hd, int nv) {
     // (n = 1024, hd 32, B = 8: 60.4 us on the LDS kernel, 44.8 us packed at 16 heads; 37.5 / 33.9 at 8 heads)
@@ -864,7 +927,7 @@ static inline void probe_mark(int which, hipStream_t stream) {
     }
 }
 
-static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block)
+static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block), bit 5: score bound from max|k| alone
 extern "C" void uwir_attn_variant(int lsv) { g_attn_lsv = lsv; }
 static inline bool attn_lsv_forced() { return g_attn_lsv >= 0 && !(g_attn_lsv & 8); }
 static inline unsigned attn_cap_lds() { return (g_attn_lsv >= 0 && (g_attn_lsv & 16)) ? 56u * 1024u : 0u; }
@@ -881,7 +944,7 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
         return uwir_set_error(UWIR_EINVAL, "flash_attn: sequence too long for the packed stream");
     hipLaunchKernelGGL((attn_pack_kernel<HD, NV>), dim3(ceil_div(npad, PK_KEYS * PK_TILES), p.heads, B), dim3(256), 0, stream,
                        (const bf16_t*)p.k, p.ldk, (const bf16_t*)p.v[0], p.ldv[0], (const bf16_t*)p.v[1], p.ldv[1], n, npad,
-                       p.heads, Kp, Vtp, (unsigned*)workspace);
+                       p.heads, Kp, Vtp, (unsigned*)workspace, (unsigned*)p.kext);
     UWIR_LAUNCH_CHECK("flash_attn(pack)");
     const int nqb = ceil_div(n, 128 * QG);
     const long long nb = (long long)nqb * p.heads * B;
@@ -981,6 +1044,8 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
     p.c = scale == 0.f ? 1.f : scale * 1.4426950408889634f;
     int nv = v2 ? 2 : 1;
     p.kmax2 = nullptr;
+    p.kext = nullptr;
+    p.norm_bound_only = (g_attn_lsv >= 0 && (g_attn_lsv & 32)) ? 1 : 0;
     p.flags = nullptr;
     // (short sequences -- ViT towers, 50 tokens -- gain nothing from the bound pre-pass: it would triple their launches)
     if (dtype == UWIR_BF16 && workspace && n >= 256) {
@@ -991,6 +1056,7 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
             return uwir_set_error(UWIR_ELAUNCH, "flash_attn: hipMemsetAsync failed");
         p.kmax2 = (const float*)workspace;
         p.flags = (int*)workspace + (size_t)B * heads;
+        p.kext = (const unsigned*)workspace + (size_t)B * heads + (size_t)ceil_div(n, 128) * heads * B;
         if (attn_packed_shape(B, n, heads, hd, nv) && workspace_bytes >= attn_packed_bytes(B, n, heads, hd, nv) &&
             ((uintptr_t)workspace & 255) == 0) {
             // the pack pre-pass also produces max|k|^2
