@@ -13,19 +13,20 @@ model = NAFNetWFIGate(**MK, precision="bf16")
 model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=0))
 model = model.cuda().eval()
 x, z, m = (t.cuda() for t in synth_student_inputs(B, S, S, 512, 10, mask_hw=(7, 7), seed=99))
+VARS = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [8, 40]
 outs = {}
-for v in (8, 40):
+for v in VARS:
     lib.uwir_attn_variant(v)
     for _ in range(3):
         out = model(x, z, m)[0]
     outs[v] = out.float().clone()
 torch.cuda.synchronize()
-d = (outs[8] - outs[40]).abs().max().item()
-mse = ((outs[8] - outs[40]) ** 2).mean().item()
+d = (outs[VARS[0]] - outs[VARS[-1]]).abs().max().item()
+mse = ((outs[VARS[0]] - outs[VARS[-1]]) ** 2).mean().item()
 print(f"max |tight - norm-only| = {d:.3e}, PSNR between them {10 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20))).item():.1f} dB")
-res = {8: [], 40: []}
+res = {v: [] for v in VARS}
 for rnd in range(3):
-    for v in (8, 40):
+    for v in VARS:
         lib.uwir_attn_variant(v)
         model(x, z, m)
         torch.cuda.synchronize()
@@ -37,4 +38,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1) / 5)
 lib.uwir_attn_variant(-1)
-print(f"{S}x{S} B{B}: tight bound " + " ".join(f"{t:.2f}" for t in res[8]) + " | norm bound only " + " ".join(f"{t:.2f}" for t in res[40]) + " ms per forward")
+print(f"{S}x{S} B{B} (8: default, 40: norm bound only, 72: 256-query fallback blocks): " + " | ".join(f"variant {v}: " + " ".join(f"{t:.2f}" for t in res[v]) for v in VARS) + " ms per forward")

@@ -40,6 +40,15 @@ def spy(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=True):
             for h in range(heads):
                 s = qf[b, :, h] @ kf[b, :, h].T                 # [ns, n]
                 tmax[b, :, h] = s.abs().amax(dim=1)
+        # all queries, per 128-query group (the unit that falls back): share of groups with any query over 90
+        qa = q.float().reshape(B_, n, -1)[:, :, :heads * hd].reshape(B_, n, heads, hd) * c
+        hia = torch.maximum(qa * kmax[:, None], qa * kmin[:, None]).sum(-1)
+        loa = torch.minimum(qa * kmax[:, None], qa * kmin[:, None]).sum(-1)
+        u0 = qa.norm(dim=-1) * kn[:, None, :]
+        u1 = torch.minimum(torch.maximum(hia, -loa), u0)
+        g0 = (u0.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
+        g1 = (u1.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
+        print(f"   128-query groups falling back: norm bound {100 * g0:5.1f}%  ->  with the per-dimension bound {100 * g1:5.1f}%")
         f = lambda t: f"max {t.max().item():6.1f} p99 {t.flatten().quantile(0.99).item():6.1f} median {t.median().item():6.1f} over90 {100 * (t > 90).float().mean().item():5.1f}%"
         print(f"n={n} heads={heads} hd={hd}: in use [{f(ub0)}] | per-dim signed [{f(ub1)}] | true max|s| [{f(tmax)}]", flush=True)
     return orig(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=fast)

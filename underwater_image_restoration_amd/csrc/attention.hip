@@ -963,7 +963,12 @@ static int launch_attn_packed(const AttnP& p, int B, void* workspace, hipStream_
         hipLaunchKernelGGL((attn_stream_kernel<HD, NV, QG, PF, 0>), grid, dim3(256), cap, stream, p, Kp, Vtp, npad, nqb, (int)nb);
     probe_mark(1, stream);
     // blocks whose score bound is too large for a fixed shift marked themselves: the online-max loop redoes them
-    hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, 2, 2>), dim3(ceil_div(n, 256), p.heads, B), dim3(256), 0, stream, p);
+    // (128-query blocks: only the marked groups are redone; 256-query blocks redo both halves of a pair when either is
+    // marked -- uwir_attn_variant bit 6 keeps them for A/B timing)
+    if (g_attn_lsv >= 0 && (g_attn_lsv & 64))
+        hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, 2, 2>), dim3(ceil_div(n, 256), p.heads, B), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((flash_attn_kernel<bf16_t, HD, NV, 1, 2>), dim3(ceil_div(n, 128), p.heads, B), dim3(256), 0, stream, p);
     UWIR_LAUNCH_CHECK("flash_attn(stream)");
     return UWIR_OK;
 }
