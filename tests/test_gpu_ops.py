@@ -810,6 +810,32 @@ def test_flash_attn_per_dimension_bound(ops, cfg):
         assert not torch.equal(t[256:], o[256:])            # the rest ran the stream kernel
 
 
+@pytest.mark.parametrize("cfg", [(1, 2048 + 19, 32, 16, 2), (1, 2048 + 5, 32, 32, 1), (1, 4096 + 30, 16, 16, 1)])
+def test_flash_attn_ragged_tail_with_very_negative_scores(ops, cfg):
+    """Packed-stream attention on a sequence that is not a multiple of 32 keys while EVERY score of every query is about
+    -50 (log2 units, inside the no-shift bound): the zero-padded keys must not reach the row sums (they used to be counted
+    as exp2(0) = 1 each and subtracted afterwards, which cancelled to 0 / 0 here)."""
+    b, n, heads, hd, nv = cfg
+    g = torch.Generator().manual_seed(5)
+    wdt = heads * hd
+    amp = 12.0 * (hd / 16) ** 0.25                          # q . k / sqrt(hd) * log2(e) stays near -52
+    u = torch.nn.functional.normalize(torch.randn(heads, hd, generator=g), dim=-1)
+    q = (u[None] * amp + 0.1 * torch.randn(n, heads, hd, generator=g)).reshape(n, wdt).bfloat16().cuda()
+    k = (-u[None] * amp + 0.3 * torch.randn(n, heads, hd, generator=g)).reshape(n, wdt).bfloat16().cuda()
+    v = torch.randn(n, wdt, generator=g).bfloat16().cuda()
+    v2 = torch.randn(n, wdt, generator=g).bfloat16().cuda() if nv == 2 else None
+    vs = [v] + ([v2] if nv == 2 else [])
+    refs = _attn_ref_cuda(q, k, vs, b, n, heads, hd)
+    o = [torch.empty(n, wdt, device="cuda") for _ in range(nv)]
+    ops.flash_attn(q, k, v, v2, b, n, heads, hd, 1.0 / math.sqrt(hd), o[0], o[1] if nv == 2 else None)
+    r = [torch.empty(n, wdt, device="cuda") for _ in range(nv)]
+    ops.flash_attn(q, k, v, v2, b, n, heads, hd, 1.0 / math.sqrt(hd), r[0], r[1] if nv == 2 else None, fast=False)
+    for got, onl, ref in zip(o, r, refs):
+        assert bool(torch.isfinite(got).all())
+        assert err(got, ref) < 3e-2 and err(onl, ref) < 3e-2
+    assert not torch.equal(o[0], r[0])                      # the stream kernel, not the online-max fallback, produced o
+
+
 def test_flash_attn_bound_band_60_to_90(ops):
     """The no-shift fast path is taken while the a-priori score bound ub = |c q| max|k| is <= 90 (log2 units).  Drive the
     (60, 90] band on the packed-stream kernel at n = 65536: every query has ub ~ 85 and keys aligned with / against the

@@ -49,6 +49,17 @@ def spy(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=True):
         g0 = (u0.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
         g1 = (u1.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
         print(f"   128-query groups falling back: norm bound {100 * g0:5.1f}%  ->  with the per-dimension bound {100 * g1:5.1f}%")
+        for G in (4, 16, 64):   # per-dimension extremes per contiguous chunk of keys: bound = max over the chunks
+            kc = kf.reshape(B_, G, n // G, heads, hd)
+            cmax, cmin = kc.amax(dim=2), kc.amin(dim=2)            # [B, G, H, D]
+            ug = torch.full_like(u0, 0.0)
+            for gi in range(G):
+                h_ = torch.maximum(qa * cmax[:, gi][:, None], qa * cmin[:, gi][:, None]).sum(-1)
+                l_ = torch.minimum(qa * cmax[:, gi][:, None], qa * cmin[:, gi][:, None]).sum(-1)
+                ug = torch.maximum(ug, torch.maximum(h_, -l_))
+            ug = torch.minimum(ug, u0)
+            gg = (ug.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
+            print(f"      {G:3d} key chunks: {100 * gg:5.1f}% of the groups (queries over 90: {100 * (ug > 90).float().mean().item():5.2f}%)")
         f = lambda t: f"max {t.max().item():6.1f} p99 {t.flatten().quantile(0.99).item():6.1f} median {t.median().item():6.1f} over90 {100 * (t > 90).float().mean().item():5.1f}%"
         print(f"n={n} heads={heads} hd={hd}: in use [{f(ub0)}] | per-dim signed [{f(ub1)}] | true max|s| [{f(tmax)}]", flush=True)
     return orig(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=fast)

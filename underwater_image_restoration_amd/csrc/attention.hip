@@ -507,7 +507,8 @@ __global__ void __launch_bounds__(256) attn_kmax_kernel(const bf16_t* __restrict
 // and the main kernel has no LDS and no barrier: every wave streams 16-byte fragments straight into registers with
 // buffer loads (per-lane offset fixed, the block offset is a scalar), two key blocks ahead of their use, for 32*QG
 // queries.  Keys in [n, npad) are packed as K = 0, V = 0, ones = 0: they add exp2(0) * 0 to every sum (without a
-// ones row the denominator's MFMA counts them as 1 each; npad - n is subtracted at the end).
+// ones row the denominators would count them as 1 each: the last block of a ragged sequence runs with their
+// exponentials masked to 0).
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -781,8 +782,12 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
 
-    auto compute = [&](auto slot_tag) {
+    // MASK (the last key block of a ragged sequence, forms without a ones row): the exponentials of the keys in
+    // [n, npad) are set to 0.  Those keys are packed as zeros, so each would add exp2(0) = 1 to a row sum; subtracting
+    // their count afterwards cancels catastrophically when every real score of a query is very negative.
+    auto compute = [&](auto slot_tag, auto mask_tag, const int keys_left) {
         constexpr int S = decltype(slot_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value != 0;
         f32x16 s[QG];
 #pragma unroll
         for (int g = 0; g < QG; ++g)
@@ -801,7 +806,12 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const f32x2 e = {__builtin_amdgcn_exp2f(s[g][8 * ss + j]), __builtin_amdgcn_exp2f(s[g][8 * ss + j + 1])};
+                    f32x2 e = {__builtin_amdgcn_exp2f(s[g][8 * ss + j]), __builtin_amdgcn_exp2f(s[g][8 * ss + j + 1])};
+                    if constexpr (MASK) {   // accumulator register r of the 32 x 32 tile = key 8 (r / 4) + 4 lh + r % 4
+                        const int r = 8 * ss + j, key = 8 * (r >> 2) + 4 * lh + (r & 3);
+                        e[0] = key < keys_left ? e[0] : 0.f;
+                        e[1] = key + 1 < keys_left ? e[1] : 0.f;
+                    }
                     if constexpr (LSV == 1 && !SUMROW) lsum[g] += e;
                     pb[g][ss][j] = (bf16_t)e[0];
                     pb[g][ss][j + 1] = (bf16_t)e[1];
@@ -829,30 +839,37 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
         }
     };
 
-    const int nblk = npad / 32;
+    const bool ragged = !SUMROW && npad != n;   // uniform: the last block then runs on its own, masked
+    const int nblk = npad / 32 - (ragged ? 1 : 0);
     int i = 0;
     if constexpr (PF == 2) {
         issue(0, GIdx<0>{});
         issue(1, GIdx<1>{});
         for (; i + 3 <= nblk; i += 3) {  // loads past the last block return zeros (buffer bounds) and are never used
             issue(i + 2, GIdx<2>{});
-            compute(GIdx<0>{});
+            compute(GIdx<0>{}, GIdx<0>{}, 32);
             issue(i + 3, GIdx<0>{});
-            compute(GIdx<1>{});
+            compute(GIdx<1>{}, GIdx<0>{}, 32);
             issue(i + 4, GIdx<1>{});
-            compute(GIdx<2>{});
+            compute(GIdx<2>{}, GIdx<0>{}, 32);
         }
-        if (i < nblk) compute(GIdx<0>{});
-        if (i + 1 < nblk) compute(GIdx<1>{});
+        if (i < nblk) compute(GIdx<0>{}, GIdx<0>{}, 32);
+        if (i + 1 < nblk) compute(GIdx<1>{}, GIdx<0>{}, 32);
     } else {
         issue(0, GIdx<0>{});
         for (; i + 2 <= nblk; i += 2) {
             issue(i + 1, GIdx<1>{});
-            compute(GIdx<0>{});
+            compute(GIdx<0>{}, GIdx<0>{}, 32);
             issue(i + 2, GIdx<0>{});
-            compute(GIdx<1>{});
+            compute(GIdx<1>{}, GIdx<0>{}, 32);
         }
-        if (i < nblk) compute(GIdx<0>{});
+        if (i < nblk) compute(GIdx<0>{}, GIdx<0>{}, 32);
+    }
+    if constexpr (!SUMROW) {
+        if (ragged) {
+            issue(nblk, GIdx<0>{});
+            compute(GIdx<0>{}, GIdx<1>{}, n - nblk * 32);
+        }
     }
 
     // ---- denominators, normalise, store (same accumulator layout as flash_attn_kernel)
@@ -866,13 +883,13 @@ __global__ void __launch_bounds__(256) attn_stream_kernel(AttnP p, const bf16_t*
             l = __uint_as_float(sw[hl]);
         } else if constexpr (LSV == 2) {   // lane n < 16 holds the sums of queries n (row 0) and n + 16 (row 1)
             const float l0 = __shfl(Lsel[g][0], lq & 15), l1 = __shfl(Lsel[g][1], lq & 15);
-            l = (lq < 16 ? l0 : l1) - (float)(npad - n);
+            l = lq < 16 ? l0 : l1;
         } else if constexpr (LSV == 1) {   // this lane's keys, then the other half-wave's (same query, the other 16 of 32)
             unsigned u = __float_as_uint(lsum[g][0] + lsum[g][1]);
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) - (float)(npad - n);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         } else {
-            l = Lacc[g][0] - (float)(npad - n);
+            l = Lacc[g][0];
         }
         const int q_idx = qbase + 32 * g;
         if (q_idx >= n) continue;
