@@ -2,6 +2,7 @@
 per sampled query (every 64th) the bound in use |c q| max_k|k|, the per-dimension signed bound
 sum_d max(c q_d kmax_d, c q_d kmin_d) (and its mirror for the minimum), and the true max |score|.
     python tools/exp/attn_bound_tight.py [size] [batch]"""
+import math
 import os
 import sys
 
@@ -49,6 +50,9 @@ def spy(q, k, v1, v2, B_, n, heads, hd, scale, o1, o2, fast=True):
         g0 = (u0.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
         g1 = (u1.reshape(B_, n // 128, 128, heads).amax(dim=2) > 90).float().mean().item()
         print(f"   128-query groups falling back: norm bound {100 * g0:5.1f}%  ->  with the per-dimension bound {100 * g1:5.1f}%")
+        vmax = max(float(v1.float().abs().max()), float(v2.float().abs().max()))
+        print("      thresholds: " + "  ".join(f"T={T}: {100 * (u1.reshape(B_, n // 128, 128, heads).amax(dim=2) > T).float().mean().item():5.1f}%" for T in (90, 96, 100, 104, 108))
+              + f"   (max|v| = {vmax:.1f}, log2 n = {math.log2(n):.0f})")
         for G in (4, 16, 64):   # per-dimension extremes per contiguous chunk of keys: bound = max over the chunks
             kc = kf.reshape(B_, G, n // G, heads, hd)
             cmax, cmin = kc.amax(dim=2), kc.amin(dim=2)            # [B, G, H, D]

@@ -944,7 +944,7 @@ static inline void probe_mark(int which, hipStream_t stream) {
     }
 }
 
-static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block), bit 5: score bound from max|k| alone
+static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block), bit 5: score bound from max|k| alone, bit 6: 256-query fallback blocks, bit 7: (QG, PF) = (4, 2) for hd16 2V
 extern "C" void uwir_attn_variant(int lsv) { g_attn_lsv = lsv; }
 static inline bool attn_lsv_forced() { return g_attn_lsv >= 0 && !(g_attn_lsv & 8); }
 static inline unsigned attn_cap_lds() { return (g_attn_lsv >= 0 && (g_attn_lsv & 16)) ? 56u * 1024u : 0u; }
@@ -1085,9 +1085,12 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
             // (QG, PF) per shape measured on MI355X (tools/bench_attn.py): hd16 1V 4.84 -> 4.72 ms with 4 query groups,
             // hd16 2V 2.29 -> 2.24 and hd32 1V 0.54 -> 0.53 with one block of prefetch (with the selector-MFMA denominators
             // hd16 2V runs 1.88 at (2, 1) and 1.83 at (4, 2)), hd32 2V 0.31 -> 0.26 with (2, 1)
+            // (end of round 2, A/B/A/B with the pre-pass: hd16 2V at (4, 1) 1.80 / 1.80 ms against 1.87 / 1.83 at (4, 2); hd16 1V at
+            // (4, 1) 5.00 / 5.01 against 4.80 / 4.67 at (4, 2).  uwir_attn_variant bit 7 keeps (4, 2) for the two-V kernel.)
             if (hd == 16) return nv == 1 ? launch_attn_packed<16, 1, 4, 2>(p, B, workspace, s)
                                          : ((g_attn_lsv >= 0 && (g_attn_lsv & 4)) ? launch_attn_packed<16, 2, 2, 1>(p, B, workspace, s)
-                                                            : launch_attn_packed<16, 2, 4, 2>(p, B, workspace, s));
+                                            : (g_attn_lsv >= 0 && (g_attn_lsv & 128)) ? launch_attn_packed<16, 2, 4, 2>(p, B, workspace, s)
+                                                            : launch_attn_packed<16, 2, 4, 1>(p, B, workspace, s));
             return nv == 1 ? launch_attn_packed<32, 1, 2, 1>(p, B, workspace, s)
                            : launch_attn_packed<32, 2, 2, 1>(p, B, workspace, s);
         }
