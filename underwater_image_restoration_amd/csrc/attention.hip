@@ -944,7 +944,7 @@ static inline void probe_mark(int which, hipStream_t stream) {
     }
 }
 
-static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block), bit 5: score bound from max|k| alone, bit 6: 256-query fallback blocks, bit 7: (QG, PF) = (4, 2) for hd16 2V
+static int g_attn_lsv = -1;   // tools/: -1 = default; bits 0-1: denominator form (see attn_stream_kernel) unless bit 3 is set, bit 2: (QG, PF) = (2, 1) instead of (4, 2) for hd16 2V, bit 4: at most two stream blocks per CU (56 KiB of unused dynamic LDS per block), bit 5: score bound from max|k| alone, bit 6: 256-query fallback blocks, bit 7: (QG, PF) = (4, 2) for hd16 2V, bit 8: (2, 1) for hd32 1V
 extern "C" void uwir_attn_variant(int lsv) { g_attn_lsv = lsv; }
 static inline bool attn_lsv_forced() { return g_attn_lsv >= 0 && !(g_attn_lsv & 8); }
 static inline unsigned attn_cap_lds() { return (g_attn_lsv >= 0 && (g_attn_lsv & 16)) ? 56u * 1024u : 0u; }
@@ -1091,6 +1091,9 @@ extern "C" int uwir_flash_attn(const void* q, int ldq, const void* k, int ldk, c
                                          : ((g_attn_lsv >= 0 && (g_attn_lsv & 4)) ? launch_attn_packed<16, 2, 2, 1>(p, B, workspace, s)
                                             : (g_attn_lsv >= 0 && (g_attn_lsv & 128)) ? launch_attn_packed<16, 2, 4, 2>(p, B, workspace, s)
                                                             : launch_attn_packed<16, 2, 4, 1>(p, B, workspace, s));
+            // (hd32 1V, A/B/A/B with the pre-pass: (4, 2) 0.474 - 0.493 ms against 0.492 - 0.526 at (2, 1) and 0.55 - 0.59 at (4, 1) for
+            // B16 n4096, 1.63 against 1.70 for B4 n16384; hd32 2V stays at (2, 1): 0.233 against 0.238 at (4, 1).  Bit 8 keeps (2, 1).)
+            if (nv == 1 && !(g_attn_lsv >= 0 && (g_attn_lsv & 256))) return launch_attn_packed<32, 1, 4, 2>(p, B, workspace, s);
             return nv == 1 ? launch_attn_packed<32, 1, 2, 1>(p, B, workspace, s)
                            : launch_attn_packed<32, 2, 2, 1>(p, B, workspace, s);
         }
