@@ -171,6 +171,8 @@ def parse_args():
     ap.add_argument("--dataset-batch", type=int, default=4, help="dataset4096 / dataset512: images per forward")
     ap.add_argument("--gather", action="store_true", help="dataset4096: also gather the restored images to rank 0")
     ap.add_argument("--sde-steps", type=int, default=100)
+    ap.add_argument("--sde-mode", default="both", choices=["both", "posterior", "sde"],
+                    help="sde: which sampler a bench step runs (both = they take turns: sde_utils.py:261-277 and :297-313)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--census", default="auto", choices=["auto", "skip"],
                     help="one extra untimed single-stream pass with HIP events around every launcher -> roofline.kernels")
@@ -287,12 +289,24 @@ def worker(args, rank: int, world: int, dist, backend, cpu_only: bool) -> int:
             unet, sde, mu, cin = build_sde(args, x, clip_in)
             enc_in = cin
 
+            sde_marks = []          # (sampler, start event, end event) per bench step, on the launch stream
+
             def consume(img_f, deg_f):  # noqa: F811
                 xt = sde.noise_state(mu)
-                return sde.reverse_posterior(xt, text_context=deg_f, image_context=img_f)
+                modes = ("posterior", "sde") if args.sde_mode == "both" else (args.sde_mode,)
+                mode = modes[len(sde_marks) % len(modes)]          # both: the samplers take turns, step by step
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn = sde.reverse_posterior if mode == "posterior" else sde.reverse_sde
+                r = fn(xt, text_context=deg_f, image_context=img_f)
+                e1.record()
+                sde_marks.append((mode, e0, e1))
+                return r
             mp_per_step = mu.shape[0] * args.size * args.size / 1e6
-            wl_name = (f"BASELINE configs[3]: IR-SDE reverse_posterior, {args.sde_steps} ConditionalUNet steps, batch "
-                       f"{mu.shape[0]} at {args.size}x{args.size}, DA-CLIP contexts, {args.precision}")
+            samplers = "reverse_posterior and reverse_sde alternating" if args.sde_mode == "both" else f"reverse_{args.sde_mode}"
+            wl_name = (f"BASELINE configs[3]: IR-SDE {samplers} (one full sample of the batch per bench step), {args.sde_steps} "
+                       f"ConditionalUNet steps + fused update each, batch {mu.shape[0]} at {args.size}x{args.size}, DA-CLIP "
+                       f"contexts, {args.precision}" + (" with the fp32 tail path (unet.precise_tail)" if args.precision == "bf16" else ""))
         elif args.workload == "dataset512":  # configs[4] shapes, weak form: Bd images per rank and step
             Bd, S = args.dataset_batch, args.dataset_size
             xd, _, md = synth_student_inputs(Bd, S, S, 512, 10, mask_hw=(7, 7), seed=99 + rank)
@@ -373,6 +387,8 @@ def worker(args, rank: int, world: int, dist, backend, cpu_only: bool) -> int:
     if dist is not None:
         dist.barrier()
     sync()
+    if args.workload == "sde" and not cpu_only:
+        sde_marks.clear()
     if ops is not None:
         ops.event_timing(True)  # HIP events around the main kernel of every flash-attention call (uwir_flash_attn_probe)
     t0 = time.perf_counter()
@@ -458,6 +474,12 @@ def worker(args, rank: int, world: int, dist, backend, cpu_only: bool) -> int:
                   else ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")},
         "roofline": roof, "parity": parity, "cpu_baseline": cpu,
     }
+    if args.workload == "sde" and not cpu_only:
+        per = {}
+        for mode, e0, e1 in sde_marks:
+            per.setdefault(mode, []).append(e0.elapsed_time(e1))
+        extra_cfg["ms_per_sample"] = {k: round(sum(v) / len(v), 2) for k, v in per.items()}
+        extra_cfg["ms_per_unet_step"] = {k: round(sum(v) / len(v) / args.sde_steps, 4) for k, v in per.items()}
     if wl_name is not None:
         line["config"] = {"workload": wl_name, "sharding": f"independent units x{world}", **extra_cfg}
         line["roofline"] = None  # the roofline leg is defined for the headline workload only

@@ -234,16 +234,21 @@ int uwir_head_conv3x3(const void* x, int x_dtype, int ldx, int B, int H, int W, 
  * The stem reads its window in place (zero padding at the WINDOW border: each window is an image of its own), the mask
  * resize samples the window of the frame-sized masks, and the head adds the window of the input frame and writes only
  * the pixels the window OWNS -- frame rows [cy0, cy1) x columns [cx0, cx1) -- straight into the output frame: no
- * gather of windows before the network and no stitch copy after it.  `win` is a DEVICE array of nwin descriptors. */
+ * gather of windows before the network and no stitch copy after it.  `win` is a DEVICE array of nwin descriptors.
+ * Descriptor contract (n_frames = F): 0 <= frame < F, 0 <= y <= FH - T, 0 <= x <= FW - T, and the owned core inside the
+ * window (y <= cy0 <= cy1 <= y + T, same for x).  The descriptors live in device memory, so the entry points cannot
+ * reject a bad one with an error code without a synchronisation; instead every kernel checks each descriptor it uses
+ * and skips a window that breaks the contract (nothing is read or written for it).  Build them on the host with the
+ * same checks (tiling.TiledRestorer.window_descriptors / ops.check_windows do). */
 typedef struct uwir_window { int frame, y, x, cy0, cy1, cx0, cx1, reserved; } uwir_window;
-int uwir_stem_conv3x3_win(const float* frames, int Cin, int FH, int FW, const uwir_window* win, int nwin, int T,
-                          const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
+int uwir_stem_conv3x3_win(const float* frames, int n_frames, int Cin, int FH, int FW, const uwir_window* win, int nwin,
+                          int T, const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
                           uwir_stream_t stream);
-int uwir_bilinear_win(const float* frames, int M, int FH, int FW, const uwir_window* win, int nwin, int T, float* dst,
-                      int ldd, int hd, int wd, uwir_stream_t stream);
+int uwir_bilinear_win(const float* frames, int n_frames, int M, int FH, int FW, const uwir_window* win, int nwin, int T,
+                      float* dst, int ldd, int hd, int wd, uwir_stream_t stream);
 int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nwin, int T, int Cin, const float* a_scale, const float* a_shift,
-                          const float* w, const float* bias, int Cout, const float* frames_in, float* frames_out, int FH,
-                          int FW, const uwir_window* win, uwir_stream_t stream);
+                          const float* w, const float* bias, int Cout, const float* frames_in, float* frames_out,
+                          int n_frames, int FH, int FW, const uwir_window* win, uwir_stream_t stream);
 
 /* ---- L/utils/sde_utils.py:44-45,177-187,205-231 fused IR-SDE reverse steps --------------------
  * euler:     x <- x - (theta*(mu-x) - sigma^2*score)*dt - sigma*(eps*sqrt(dt)),  score = -noise/sigma_bar

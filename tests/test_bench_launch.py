@@ -42,3 +42,37 @@ def test_launcher_reports_a_failing_rank():
         assert launch_local_ranks(script, [], 2) == 7
     finally:
         os.remove(script)
+
+
+def _write(name, body):
+    script = os.path.join(ROOT, "tests", name)
+    with open(script, "w") as f:
+        f.write(body)
+    return script
+
+
+def test_launcher_does_not_hang_when_a_peer_dies_under_a_blocked_rank0():
+    """Rank 1 exits 7 while rank 0 blocks for ever (as it would inside a rendezvous or an RCCL barrier): the launcher must
+    terminate rank 0 by PID and return 7 within seconds, not wait for rank 0's stdout to close."""
+    import time
+    from underwater_image_restoration_amd.shard import launch_local_ranks
+    script = _write("_blocked_rank0.py", "import os, sys, time\nif os.environ['RANK'] == '1':\n    time.sleep(0.3)\n    sys.exit(7)\n"
+                    "print('rank0 waiting', flush=True)\ntime.sleep(3600)\n")
+    try:
+        t0 = time.monotonic()
+        assert launch_local_ranks(script, [], 2) == 7
+        assert time.monotonic() - t0 < 20
+    finally:
+        os.remove(script)
+
+
+def test_launcher_deadline_kills_every_rank():
+    import time
+    from underwater_image_restoration_amd.shard import launch_local_ranks
+    script = _write("_all_blocked.py", "import signal, time\nsignal.signal(signal.SIGTERM, signal.SIG_IGN)\ntime.sleep(3600)\n")
+    try:
+        t0 = time.monotonic()
+        assert launch_local_ranks(script, [], 2, deadline_s=1.0) == 124      # SIGTERM ignored -> SIGKILL after 5 s
+        assert time.monotonic() - t0 < 30
+    finally:
+        os.remove(script)

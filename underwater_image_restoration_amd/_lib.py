@@ -85,9 +85,9 @@ _SIGS = {
     "uwir_bilinear_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
     "uwir_stem_conv3x3": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
-    "uwir_stem_conv3x3_win": (ci, [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
-    "uwir_bilinear_win": (ci, [vp, ci, ci, ci, vp, ci, ci, vp, ci, ci, ci, vp]),
-    "uwir_head_conv3x3_win": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
+    "uwir_stem_conv3x3_win": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "uwir_bilinear_win": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, ci, ci, ci, vp]),
+    "uwir_head_conv3x3_win": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp]),
     "uwir_sde_euler_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_sde_posterior_step": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, vp]),
     "uwir_ln_rows": (ci, [vp, ci, sz, ci, ci, vp, ci, ci, vp, vp, cf, vp, sz, vp, ci, sz, vp]),

@@ -610,12 +610,23 @@ extern "C" int uwir_softmax_rows(const float* x, int ldx, int B, int C, const fl
     return UWIR_OK;
 }
 
+// A window descriptor (device memory, caller-built) is trusted only after this check: every kernel that takes `win`
+// evaluates it per block / element and LEAVES without touching memory when it fails, so a bad descriptor handed through
+// the public C ABI writes nothing instead of reading or writing outside the frames.  NF = number of frames.
+__device__ __forceinline__ bool window_ok(const uwir_window& w, int NF, int FH, int FW, int T) {
+    return w.frame >= 0 && w.frame < NF && w.y >= 0 && w.x >= 0 && w.y <= FH - T && w.x <= FW - T;
+}
+__device__ __forceinline__ bool window_core_ok(const uwir_window& w, int T) {
+    return w.cy0 >= w.y && w.cy1 <= w.y + T && w.cx0 >= w.x && w.cx1 <= w.x + T && w.cy0 <= w.cy1 && w.cx0 <= w.cx1;
+}
+
 // ------------------------------------------------------------------------------------------
 // bilinear resize (align_corners=False, no antialias), NCHW source -> NHWC destination columns
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ src, int B, int M, int hs, int ws,
                                                        float* __restrict__ dst, int ldd, int hd, int wd, float sy,
-                                                       float sx, const uwir_window* __restrict__ win, int FH, int FW) {
+                                                       float sx, const uwir_window* __restrict__ win, int FH, int FW,
+                                                       int NF) {
     size_t total = (size_t)B * hd * wd * M;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int m = (int)(i % M);
@@ -631,6 +642,7 @@ __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__
         int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
         float ly = fy - (float)y0, lx = fx - (float)x0;
         // plain batch: image b is contiguous; windows: image b is the hs x ws window of frame win[b].frame at (y, x)
+        if (win && !window_ok(win[b], NF, FH, FW, hs)) continue;
         const float* s = win ? src + (((size_t)win[b].frame * M + m) * FH + win[b].y) * FW + win[b].x
                              : src + ((size_t)b * M + m) * hs * ws;
         const int rs = win ? FW : ws;
@@ -647,18 +659,18 @@ extern "C" int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs
     UWIR_CHECK(B > 0 && M > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && ldd >= M, "bilinear: bad shape");
     size_t total = (size_t)B * hd * wd * M;
     hipLaunchKernelGGL(bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, B, M, hs, ws,
-                       dst, ldd, hd, wd, (float)hs / (float)hd, (float)ws / (float)wd, (const uwir_window*)nullptr, 0, 0);
+                       dst, ldd, hd, wd, (float)hs / (float)hd, (float)ws / (float)wd, (const uwir_window*)nullptr, 0, 0, 0);
     UWIR_LAUNCH_CHECK("bilinear");
     return UWIR_OK;
 }
 
-extern "C" int uwir_bilinear_win(const float* frames, int M, int FH, int FW, const uwir_window* win, int nwin, int T,
-                                 float* dst, int ldd, int hd, int wd, uwir_stream_t stream) {
+extern "C" int uwir_bilinear_win(const float* frames, int n_frames, int M, int FH, int FW, const uwir_window* win, int nwin,
+                                 int T, float* dst, int ldd, int hd, int wd, uwir_stream_t stream) {
     UWIR_CHECK(frames && win && dst, "bilinear_win: null pointer");
-    UWIR_CHECK(nwin > 0 && M > 0 && T > 0 && T <= FH && T <= FW && hd > 0 && wd > 0 && ldd >= M, "bilinear_win: bad shape");
+    UWIR_CHECK(n_frames > 0 && nwin > 0 && M > 0 && T > 0 && T <= FH && T <= FW && hd > 0 && wd > 0 && ldd >= M, "bilinear_win: bad shape");
     size_t total = (size_t)nwin * hd * wd * M;
     hipLaunchKernelGGL(bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, nwin, M, T, T, dst,
-                       ldd, hd, wd, (float)T / (float)hd, (float)T / (float)wd, win, FH, FW);
+                       ldd, hd, wd, (float)T / (float)hd, (float)T / (float)wd, win, FH, FW, n_frames);
     UWIR_LAUNCH_CHECK("bilinear_win");
     return UWIR_OK;
 }
@@ -709,9 +721,10 @@ template <typename TO>
 __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict__ x, int B, int Cin, int H, int W,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          int Cout, TO* __restrict__ out, int ldo,
-                                                         const uwir_window* __restrict__ win, int FH, int FW) {
+                                                         const uwir_window* __restrict__ win, int FH, int FW, int NF) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (ox >= W || oy >= H) return;
+    if (win && !window_ok(win[b], NF, FH, FW, H)) return;
     // plain batch: image b is contiguous NCHW; windows: image b is the H x W window of frame win[b].frame at (y, x) --
     // the conv still pads with zeros at the WINDOW border (every window is an image of its own to the network)
     const size_t plane = win ? (size_t)FH * FW : (size_t)H * W;
@@ -753,10 +766,10 @@ extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int
     if (Cin <= 4 && Cout % 16 == 0 && B <= 65535 && ceil_div(H, 4) <= 65535) {
         if (out_dtype == UWIR_BF16)
             hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
-                               x_nchw, B, Cin, H, W, w, bias, Cout, (bf16_t*)outv, ldo, (const uwir_window*)nullptr, 0, 0);
+                               x_nchw, B, Cin, H, W, w, bias, Cout, (bf16_t*)outv, ldo, (const uwir_window*)nullptr, 0, 0, 0);
         else
             hipLaunchKernelGGL(stem_pixel_kernel<float>, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
-                               x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo, (const uwir_window*)nullptr, 0, 0);
+                               x_nchw, B, Cin, H, W, w, bias, Cout, out, ldo, (const uwir_window*)nullptr, 0, 0, 0);
         UWIR_LAUNCH_CHECK("stem(pixel)");
         return UWIR_OK;
     }
@@ -768,19 +781,20 @@ extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int
     return UWIR_OK;
 }
 
-extern "C" int uwir_stem_conv3x3_win(const float* frames, int Cin, int FH, int FW, const uwir_window* win, int nwin, int T,
-                                     const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
+extern "C" int uwir_stem_conv3x3_win(const float* frames, int n_frames, int Cin, int FH, int FW, const uwir_window* win,
+                                     int nwin, int T, const float* w, const float* bias, int Cout, void* out, int out_dtype, int ldo,
                                      uwir_stream_t stream) {
     UWIR_CHECK(frames && win && w && out, "stem_win: null pointer");
     UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "stem_win: bad output dtype");
-    UWIR_CHECK(nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && ldo >= Cout && ldo % 4 == 0, "stem_win: bad shape");
+    UWIR_CHECK(n_frames > 0 && nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && ldo >= Cout && ldo % 4 == 0,
+               "stem_win: bad shape");
     UWIR_CHECK(Cin >= 1 && Cin <= 4 && Cout % 16 == 0, "stem_win: needs Cin <= 4 and Cout %% 16 == 0");
     if (out_dtype == UWIR_BF16)
         hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream,
-                           frames, nwin, Cin, T, T, w, bias, Cout, (bf16_t*)out, ldo, win, FH, FW);
+                           frames, nwin, Cin, T, T, w, bias, Cout, (bf16_t*)out, ldo, win, FH, FW, n_frames);
     else
         hipLaunchKernelGGL(stem_pixel_kernel<float>, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream,
-                           frames, nwin, Cin, T, T, w, bias, Cout, (float*)out, ldo, win, FH, FW);
+                           frames, nwin, Cin, T, T, w, bias, Cout, (float*)out, ldo, win, FH, FW, n_frames);
     UWIR_LAUNCH_CHECK("stem_win");
     return UWIR_OK;
 }
@@ -866,7 +880,7 @@ __global__ void __launch_bounds__(256) head_tile_kernel(const TX* __restrict__ x
                                                         const float* __restrict__ bias, int Cout,
                                                         const float* __restrict__ res, float* __restrict__ out,
                                                         float* __restrict__ preclamp, int Ho, int Wo, int do_clamp,
-                                                        const uwir_window* __restrict__ win, int FH, int FW) {
+                                                        const uwir_window* __restrict__ win, int FH, int FW, int NF) {
     constexpr int PH = HT_H + 2, PW = HT_W + 2, NPIX = PH * PW;
     __shared__ __attribute__((aligned(16))) float tile[NPIX * HT_PS];
     const int tid = threadIdx.x, tx = tid % HT_W, ty = tid / HT_W;
@@ -876,6 +890,7 @@ __global__ void __launch_bounds__(256) head_tile_kernel(const TX* __restrict__ x
     uwir_window wd = {0, 0, 0, 0, 0, 0, 0, 0};
     if (win) {
         wd = win[b];
+        if (!window_ok(wd, NF, FH, FW, H) || !window_core_ok(wd, H)) return;
         if (wd.y + y0 >= wd.cy1 || wd.y + y0 + HT_H <= wd.cy0 || wd.x + x0 >= wd.cx1 || wd.x + x0 + HT_W <= wd.cx0) return;
     }
     float acc[HEAD_MAX_COUT] = {0.f, 0.f, 0.f, 0.f};
@@ -952,11 +967,11 @@ extern "C" int uwir_head_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
         if (x_dtype == UWIR_BF16)
             hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0,
                                (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout,
-                               residual_nchw, out_nchw, preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0);
+                               residual_nchw, out_nchw, preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0, 0);
         else
             hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0,
                                (hipStream_t)stream, x, ldx, H, W, Cin, a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw,
-                               preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0);
+                               preclamp_nchw, H, W, 1, (const uwir_window*)nullptr, 0, 0, 0);
         UWIR_LAUNCH_CHECK("head(tile)");
         return UWIR_OK;
     }
@@ -972,10 +987,10 @@ extern "C" int uwir_head_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
 
 extern "C" int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nwin, int T, int Cin, const float* a_scale,
                                      const float* a_shift, const float* w, const float* bias, int Cout,
-                                     const float* frames_in, float* frames_out, int FH, int FW, const uwir_window* win,
-                                     uwir_stream_t stream) {
+                                     const float* frames_in, float* frames_out, int n_frames, int FH, int FW,
+                                     const uwir_window* win, uwir_stream_t stream) {
     UWIR_CHECK(x && w && frames_in && frames_out && win, "head_win: null pointer");
-    UWIR_CHECK(nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && Cin % HT_CC == 0 && Cout >= 1 &&
+    UWIR_CHECK(n_frames > 0 && nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && Cin % HT_CC == 0 && Cout >= 1 &&
                    Cout <= HEAD_MAX_COUT && ldx >= Cin && ldx % 4 == 0,
                "head_win: bad shape (Cin %% 16 == 0, Cout <= %d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head_win: a_scale/a_shift must come together");
@@ -983,11 +998,11 @@ extern "C" int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nw
     if (x_dtype == UWIR_BF16)
         hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0,
                            (hipStream_t)stream, (const bf16_t*)x, ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in,
-                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW);
+                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW, n_frames);
     else
         hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0,
                            (hipStream_t)stream, (const float*)x, ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in,
-                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW);
+                           frames_out, (float*)nullptr, T, T, 1, win, FH, FW, n_frames);
     UWIR_LAUNCH_CHECK("head_win");
     return UWIR_OK;
 }
@@ -1101,11 +1116,11 @@ extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
             hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0,
                                (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr,
                                w, bias, Cout, (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0,
-                               (const uwir_window*)nullptr, 0, 0);
+                               (const uwir_window*)nullptr, 0, 0, 0);
         else
             hipLaunchKernelGGL(head_tile_kernel<float>, dim3(ceil_div(Wo, HT_W), ceil_div(Ho, HT_H), B), dim3(256), 0,
                                (hipStream_t)stream, x, ldx, H, W, Cin, (const float*)nullptr, (const float*)nullptr, w, bias,
-                               Cout, (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0, (const uwir_window*)nullptr, 0, 0);
+                               Cout, (const float*)nullptr, out_nchw, (float*)nullptr, Ho, Wo, 0, (const uwir_window*)nullptr, 0, 0, 0);
         UWIR_LAUNCH_CHECK("tail(tile)");
         return UWIR_OK;
     }

@@ -300,33 +300,54 @@ def head_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, a_scale, a_s
                                      _p(residual_nchw), _p(out_nchw), _p(preclamp_nchw), _stream(x)), "head_conv3x3")
 
 
+def check_windows(rows, n_frames: int, FH: int, FW: int, T: int) -> None:
+    """Host-side check of ``uwir_window`` records (a sequence of [frame, y, x, cy0, cy1, cx0, cx1, reserved] rows BEFORE
+    they go to the device): the contract of include/uwir.h.  The kernels skip a window that breaks it; this raises."""
+    for r in rows:
+        f, y, x, cy0, cy1, cx0, cx1 = (int(v) for v in r[:7])
+        if not (0 <= f < n_frames and 0 <= y <= FH - T and 0 <= x <= FW - T):
+            raise ValueError(f"window {list(r)}: frame / origin outside {n_frames} frames of {FH} x {FW} at window edge {T}")
+        if not (y <= cy0 <= cy1 <= y + T and x <= cx0 <= cx1 <= x + T):
+            raise ValueError(f"window {list(r)}: owned core outside the window")
+
+
+def _win_ok(win: torch.Tensor, frames: torch.Tensor, what: str) -> None:
+    if (win.dtype != torch.int32 or win.dim() != 2 or win.shape[1] != 8 or not win.is_contiguous()
+            or win.device != frames.device):
+        raise ValueError(f"{what}: win must be a contiguous int32 [nwin, 8] tensor on the frames' device")
+
+
 def stem_conv3x3_win(frames: torch.Tensor, win: torch.Tensor, T: int, w, bias, out: torch.Tensor) -> None:
     """Stem conv over the T x T windows `win` (int32 [nwin, 8] device descriptors, see uwir_window) of NCHW frames."""
     _f32(frames, w, bias)
-    if frames.dim() != 4 or not frames.is_contiguous() or win.dtype != torch.int32 or not win.is_contiguous() or win.shape[1] != 8:
-        raise ValueError("stem_conv3x3_win: frames must be contiguous NCHW, win an int32 [nwin, 8] tensor")
-    _, Cin, FH, FW = frames.shape
-    _lib.check(_lib.load().uwir_stem_conv3x3_win(_p(frames), Cin, FH, FW, _p(win), win.shape[0], T, _p(w), _p(bias), w.shape[-1],
-                                                 _p(out), _dt(out), _ld(out), _stream(frames)), "stem_conv3x3_win")
+    if frames.dim() != 4 or not frames.is_contiguous():
+        raise ValueError("stem_conv3x3_win: frames must be contiguous NCHW")
+    _win_ok(win, frames, "stem_conv3x3_win")
+    NF, Cin, FH, FW = frames.shape
+    _lib.check(_lib.load().uwir_stem_conv3x3_win(_p(frames), NF, Cin, FH, FW, _p(win), win.shape[0], T, _p(w), _p(bias),
+                                                 w.shape[-1], _p(out), _dt(out), _ld(out), _stream(frames)), "stem_conv3x3_win")
 
 
 def bilinear_win(frames: torch.Tensor, win: torch.Tensor, T: int, dst: torch.Tensor, hd: int, wd: int) -> None:
     _f32(frames, dst)
-    if frames.dim() != 4 or not frames.is_contiguous() or win.dtype != torch.int32 or not win.is_contiguous():
-        raise ValueError("bilinear_win: frames must be contiguous NCHW, win an int32 [nwin, 8] tensor")
-    _, M, FH, FW = frames.shape
-    _lib.check(_lib.load().uwir_bilinear_win(_p(frames), M, FH, FW, _p(win), win.shape[0], T, _p(dst), _ld(dst), hd, wd,
+    if frames.dim() != 4 or not frames.is_contiguous():
+        raise ValueError("bilinear_win: frames must be contiguous NCHW")
+    _win_ok(win, frames, "bilinear_win")
+    NF, M, FH, FW = frames.shape
+    _lib.check(_lib.load().uwir_bilinear_win(_p(frames), NF, M, FH, FW, _p(win), win.shape[0], T, _p(dst), _ld(dst), hd, wd,
                                              _stream(frames)), "bilinear_win")
 
 
 def head_conv3x3_win(x: torch.Tensor, T: int, Cin: int, a_scale, a_shift, w, bias, Cout: int, frames_in: torch.Tensor,
                      frames_out: torch.Tensor, win: torch.Tensor) -> None:
     _f32(a_scale, a_shift, w, bias, frames_in, frames_out)
-    if frames_in.shape != frames_out.shape or not frames_in.is_contiguous() or not frames_out.is_contiguous():
+    if (frames_in.dim() != 4 or frames_in.shape != frames_out.shape or not frames_in.is_contiguous()
+            or not frames_out.is_contiguous()):
         raise ValueError("head_conv3x3_win: frames must be contiguous NCHW tensors of one shape")
-    _, _, FH, FW = frames_in.shape
+    _win_ok(win, frames_in, "head_conv3x3_win")
+    NF, _, FH, FW = frames_in.shape
     _lib.check(_lib.load().uwir_head_conv3x3_win(_p(x), _dt(x), _ld(x), win.shape[0], T, Cin, _p(a_scale), _p(a_shift), _p(w), _p(bias),
-                                                 Cout, _p(frames_in), _p(frames_out), FH, FW, _p(win), _stream(x)),
+                                                 Cout, _p(frames_in), _p(frames_out), NF, FH, FW, _p(win), _stream(x)),
                "head_conv3x3_win")
 
 

@@ -233,7 +233,13 @@ class IRSDE:
         from PIL import Image
         os.makedirs(save_dir, exist_ok=True)
         x_l, x_r = x.chunk(2, dim=1)
-        img = state_grid_uint8(torch.cat([x_l, x_r], dim=3))   # (odd channel counts fail here, as in the reference)
+        if x_l.shape[1] != x_r.shape[1]:
+            raise RuntimeError("save_states: the two channel halves of the state differ in size (odd channel count); "
+                               "torch.cat fails here in the reference too (sde_utils.py:272)")
+        if x_l.shape[1] not in (1, 3):
+            raise ValueError(f"save_states: {x_l.shape[1]}-channel halves cannot be written as an image (PIL, like "
+                             "torchvision.utils.save_image, takes 1 or 3 channels)")
+        img = state_grid_uint8(torch.cat([x_l, x_r], dim=3))
         arr = img.numpy()
         Image.fromarray(arr if arr.shape[2] == 3 else arr[:, :, 0]).save(f"{save_dir}/state_{t // interval}.png")
 
@@ -241,7 +247,9 @@ class IRSDE:
         T = self.sample_T if T < 0 else T
         x = xt.clone().contiguous().float()
         # a ConditionalUNet of this package derives everything that depends on (t, contexts) alone for the whole loop in
-        # one batched pass (unet.conditioning_schedule); any other callable is stepped as the reference does
+        # one batched pass (unet.conditioning_schedule); any other callable is stepped as the reference does.  Contract:
+        # the context tensors and the model's weights are not modified while the loop runs (the schedule notices an
+        # in-place edit of a context through tensor._version and then recomputes per step like the reference)
         sched = getattr(self.model, "conditioning_schedule", None)
         ok = sched is not None and x.is_cuda and set(kwargs) <= {"text_context", "image_context"}
         ctx = (sched([t * self.sample_scale for t in range(1, T + 1)], x.shape[0], device=x.device, **kwargs) if ok

@@ -15,6 +15,8 @@ import os
 import socket
 import subprocess
 import sys
+import threading
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -101,7 +103,7 @@ def restore_frame_sharded(restorer, x: torch.Tensor, cond: torch.Tensor, masks: 
         # kernel-side tiling: every rank writes the cores ITS windows own into a zero frame; every pixel is owned by
         # exactly one window, so the SUM-reduce to `dst` over xGMI (24.9 MB at 1080p) IS the stitched frame
         local = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
-        desc = restorer.window_descriptors(x.shape[0], tiles, x.device).view(x.shape[0], len(tiles), 8)[:, lo:hi]
+        desc = restorer.window_descriptors(x.shape[0], tiles, x.device, (H, W)).view(x.shape[0], len(tiles), 8)[:, lo:hi]
         if hi > lo:
             restorer.restore_windows_inplace(x, cond, fm, desc.reshape(-1, 8).contiguous(), local)
         dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM)
@@ -117,37 +119,91 @@ def restore_frame_sharded(restorer, x: torch.Tensor, cond: torch.Tensor, masks: 
     return restorer.stitch(allw.transpose(0, 1), tiles, H, W)
 
 
-def launch_local_ranks(script: str, argv: Sequence[str], n_ranks: int, extra_env: Optional[dict] = None) -> int:
+def launch_local_ranks(script: str, argv: Sequence[str], n_ranks: int, extra_env: Optional[dict] = None,
+                       deadline_s: Optional[float] = None, poll_s: float = 0.2) -> int:
     """Start ``n_ranks`` copies of ``python script *argv`` on THIS node, one per GPU, with the ``torchrun`` environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and wait for them: what
     ``python -m torch.distributed.run --nproc-per-node N`` does, for callers that were started as a bare
     ``python bench.py --gpus N``.  Must be called BEFORE the calling process touches the GPU (it only waits; a process
     that has initialised HIP must not exec, and holding a context on GPU 0 next to rank 0 would skew the run).
-    Rank 0's stdout is relayed line by line; every rank inherits stderr.  If a rank fails the others are terminated
-    (by PID).  -> 0 when every rank exited 0, else the first non-zero exit code."""
+
+    Rank 0's stdout is relayed line by line by a reader thread; the ranks above 0 send their stdout to this process's
+    stderr (their diagnostics stay visible, the result stream stays rank 0's); every rank inherits stderr.  The main
+    thread polls ALL ranks: the first non-zero exit terminates the others at once (by PID: SIGTERM, SIGKILL after 5 s),
+    so a rank that dies while its peers sit in rendezvous or a collective cannot hang the run.  ``deadline_s`` (default
+    ``$UWIR_LAUNCH_DEADLINE_S`` or 3300) bounds the whole call: past it every child is killed and 124 is returned.
+    The rendezvous port stays bound (SO_REUSEADDR) by this process until just before rank 0 is started.
+    -> 0 when every rank exited 0, else the first non-zero exit code seen."""
     if n_ranks < 1:
         raise ValueError("n_ranks must be >= 1")
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("UWIR_LAUNCH_DEADLINE_S", "3300"))
     sock = socket.socket()
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
-    sock.close()
-    procs = []
-    for r in range(n_ranks):
+    procs: List[subprocess.Popen] = []
+
+    def spawn(r: int) -> subprocess.Popen:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n_ranks))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
         env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable, "-u", script, *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    for line in procs[0].stdout:          # rank 0 prints the result line(s)
-        sys.stdout.write(line)
-        sys.stdout.flush()
+        return subprocess.Popen([sys.executable, "-u", script, *argv], env=env,
+                                stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0))
+
+    def relay(stream) -> None:
+        try:
+            for line in stream:          # rank 0 prints the result line(s)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+        except ValueError:               # stream closed under us after a kill
+            pass
+
+    def stop_all() -> None:
+        live = [q for q in procs if q is not None]
+        for q in live:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + 5.0
+        for q in live:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    t0 = time.monotonic()
+    reader = None
     rc = 0
-    for p in procs:
-        code = p.wait()
-        if code != 0 and rc == 0:
-            rc = code
-            for q in procs:
-                if q.poll() is None:
-                    q.terminate()
+    try:
+        # ranks above 0 first (they only connect), rank 0 (which binds MASTER_PORT) right after the port is released
+        procs = [None] * n_ranks  # type: ignore[list-item]
+        for r in range(n_ranks - 1, 0, -1):
+            procs[r] = spawn(r)
+        sock.close()
+        procs[0] = spawn(0)
+        reader = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+        reader.start()
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > deadline_s:
+                sys.stderr.write(f"launch_local_ranks: deadline of {deadline_s:.0f} s passed, killing {n_ranks} ranks\n")
+                rc = 124
+                break
+            time.sleep(poll_s)
+    finally:
+        try:
+            sock.close()
+        except OSError:
+            pass
+        stop_all()
+        if reader is not None:
+            reader.join(timeout=5.0)
     return rc

@@ -101,13 +101,17 @@ class TiledRestorer:
             out[:, :, t.cy0:t.cy1, t.cx0:t.cx1] = win[:, i, :, t.cy0 - t.wy:t.cy1 - t.wy, t.cx0 - t.wx:t.cx1 - t.wx]
         return out
 
-    def window_descriptors(self, n_frames: int, tiles: List[Tile], device) -> torch.Tensor:
-        """int32 [n_frames * len(tiles), 8] device array of ``uwir_window`` records (frame-major), cached per plan."""
-        key = (n_frames, tuple(tiles), str(device))
+    def window_descriptors(self, n_frames: int, tiles: List[Tile], device, frame_hw=None) -> torch.Tensor:
+        """int32 [n_frames * len(tiles), 8] device array of ``uwir_window`` records (frame-major), cached per plan.
+        ``frame_hw`` = (FH, FW) of the frames the windows index: the records are checked against it on the host before
+        they go to the device (ops.check_windows: the contract of include/uwir.h)."""
+        key = (n_frames, tuple(tiles), str(device), frame_hw)
         cache = self.__dict__.setdefault("_desc_cache", {})
         d = cache.get(key)
         if d is None:
             rows = [[f, t.wy, t.wx, t.cy0, t.cy1, t.cx0, t.cx1, 0] for f in range(n_frames) for t in tiles]
+            if frame_hw is not None:
+                ops.check_windows(rows[:len(tiles)], n_frames, frame_hw[0], frame_hw[1], self.tile)
             d = torch.tensor(rows, dtype=torch.int32).to(device)
             if len(cache) > 16:
                 cache.clear()
@@ -140,7 +144,7 @@ class TiledRestorer:
         if getattr(self.model, "supports_windows", False) and x.is_cuda:
             out = torch.empty(x.shape, dtype=torch.float32, device=x.device)   # every pixel is owned by exactly one window
             self.restore_windows_inplace(x, cond, None if fm is None else fm.contiguous(), self.window_descriptors(
-                x.shape[0], tiles, x.device), out)
+                x.shape[0], tiles, x.device, (H, W)), out)
             return out
         return self.stitch(self.run_windows(x, cond, fm, tiles), tiles, H, W)   # generic callables: gather / stitch copies
 

@@ -69,6 +69,7 @@ class ConditionalUNet(nn.Module):
                     p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
         self._pack: Optional[dict] = None
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self.precise_tail = True             # bf16: catF / final res_conv / final ResBlock output in fp32 (see forward)
         self.fused_linattn = True            # bf16: Residual(PreNorm(LinearAttention)) as two fused passes (csrc/linattn.hip)
         self._emb_cache: Dict[tuple, torch.Tensor] = {}
         self._schedule: Optional[dict] = None   # conditioning_schedule()
@@ -126,6 +127,9 @@ class ConditionalUNet(nn.Module):
             r["wres"] = conv(sd[p + "res_conv.weight"]) if (p + "res_conv.weight") in sd else None
             return r
 
+        def conv32(w: torch.Tensor) -> torch.Tensor:
+            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(f32).contiguous()
+
         ov_w, ov_b, ov_off = [], [], [0]
 
         def geglu_rows(w: torch.Tensor) -> torch.Tensor:
@@ -181,6 +185,8 @@ class ConditionalUNet(nn.Module):
                      b_up=vec(sd[key + "bias"]) if (key + "bias") in sd else None)
             pk["ups"].append(u)
         pk["final"] = resblock("final_res_block.")
+        if "final_res_block.res_conv.weight" in sd:     # precise tail path (bf16 mode): the last 1x1 at fp32
+            pk["final"]["wres32"] = conv32(sd["final_res_block.res_conv.weight"])
         pk["tail_w"] = sd["final_conv.weight"].permute(0, 2, 3, 1).to(f32).contiguous()  # [Cout,3,3,Cin]
         pk["tail_b"] = vec(sd["final_conv.bias"])
         pk["ss_w"], pk["ss_b"] = torch.cat(ss_w, dim=0).contiguous(), torch.cat(ss_b, dim=0).contiguous()
@@ -231,15 +237,20 @@ class ConditionalUNet(nn.Module):
             self._emb_cache[key] = emb
         return emb
 
-    def _resblock(self, r: dict, x: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, ss_all: torch.Tensor, tag: str):
-        """ResBlock (module_util.py:131-153): x [M, din] view -> out [M, dout] view (stream dtype)."""
+    def _resblock(self, r: dict, x: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, ss_all: torch.Tensor, tag: str,
+                  precise_res: bool = False):
+        """ResBlock (module_util.py:131-153): x [M, din] view -> out [M, dout] view (stream dtype).  ``precise_res``: the
+        1x1 ``res_conv`` runs on fp32 rows with fp32 weights into an fp32 buffer (the precise tail path of bf16 mode)."""
         M, dev, adt = B * H * W, x.device, self._pack["adt"]
         din, dout, off = r["din"], r["dout"], r["off"]
         h = self._buf(tag + "h", M, dout, adt, dev)
         ops.conv_gemm(x, r["w1"], h, B=B, H=H, W=W, C_=din, N=dout, KH=3, KW=3, pad=1,
                       batch_scale=ss_all[:, off:off + dout], batch_bias=ss_all[:, off + dout:off + 2 * dout], act=ops.ACT_SILU)
         res = x
-        if r["wres"] is not None:
+        if r["wres"] is not None and precise_res and x.dtype == torch.float32 and "wres32" in r:
+            res = self._buf(tag + "r32", M, dout, torch.float32, dev)
+            ops.conv_gemm(x, r["wres32"], res, B=B, H=H, W=W, C_=din, N=dout)
+        elif r["wres"] is not None:
             res = self._buf(tag + "r", M, dout, adt, dev)
             ops.conv_gemm(x, r["wres"], res, B=B, H=H, W=W, C_=din, N=dout)
         ops.conv_gemm(h, r["w2"], out, B=B, H=H, W=W, C_=dout, N=dout, KH=3, KW=3, pad=1, act=ops.ACT_SILU, res=res)
@@ -298,8 +309,6 @@ class ConditionalUNet(nn.Module):
         ops.add_rows(y, x, out)                                                                          # Residual: + x
 
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    @ops.on_operand_device
     def _conditioning_rows(self, emb: torch.Tensor, R: int, B: int, text_context, image_context, dev, tag: str):
         """emb [R, nf] (R = B, or T * B for a schedule) -> (ss_all [R, S], u_all [B, U] or None, st [R, td])."""
         pk, f32, td = self._pack, torch.float32, 4 * self.nf
@@ -332,11 +341,16 @@ class ConditionalUNet(nn.Module):
         if sch is not None and not torch.is_tensor(time):
             i = sch["index"].get(float(time))
             if (i is not None and sch["B"] == B and sch["dev"] == dev and sch["text"] is text_context
-                    and sch["image"] is image_context):
+                    and sch["image"] is image_context and sch["pack"] is self._pack
+                    and sch["versions"] == self._ctx_versions(text_context, image_context)):
                 return sch["ss"][i], sch["u"]
         emb = self._time_embedding(time, B, dev)
         ss_all, u_all, _ = self._conditioning_rows(emb, B, B, text_context, image_context, dev, "")
         return ss_all, u_all
+
+    @staticmethod
+    def _ctx_versions(*ts):
+        return tuple(None if t is None else t._version for t in ts)
 
     @contextlib.contextmanager
     def conditioning_schedule(self, times, B: int, text_context=None, image_context=None, device=None):
@@ -344,7 +358,8 @@ class ConditionalUNet(nn.Module):
         softmax, every ResBlock's (scale + 1 | shift) vector, the cross-attention constants -- for ALL ``times`` of a
         sampling loop in one batched pass (6 tiny launches per step otherwise: 0.15 of 5.5 ms at B = 8, 256 x 256).
         Inside the ``with`` block, forward() calls with one of these scalar times, this batch size and these very
-        context tensors take their rows from it; anything else is computed as usual.  Row results of ``ops.linear`` do
+        context tensors take their rows from it; anything else is computed as usual -- including calls after an in-place
+        edit of a context tensor (``tensor._version`` is recorded) or a weight reload (the pack's identity is recorded).  Row results of ``ops.linear`` do
         not depend on how many rows share a launch, so the outputs are bit-identical."""
         if self._pack is None:
             self._pack = self._build_pack()
@@ -355,13 +370,18 @@ class ConditionalUNet(nn.Module):
             emb = torch.cat([self._time_embedding(t, B, dev) for t in times], 0)
             ss, u, _ = self._conditioning_rows(emb, len(times) * B, B, text_context, image_context, dev, "sch_")
         prev = self._schedule
+        if prev is not None:      # nested schedule: the "sch_" buffers are keyed by shape only, keep the outer one's rows
+            ss, u = ss.clone(), (None if u is None else u.clone())
         self._schedule = dict(index={t: i for i, t in enumerate(times)}, B=B, dev=dev, text=text_context, image=image_context,
-                              ss=ss.view(len(times), B, -1), u=u)
+                              ss=ss.view(len(times), B, -1), u=u, pack=self._pack,
+                              versions=self._ctx_versions(text_context, image_context))
         try:
             yield self
         finally:
             self._schedule = prev
 
+    @torch.no_grad()
+    @ops.on_operand_device
     def forward(self, xt: torch.Tensor, cond: torch.Tensor, time, text_context: Optional[torch.Tensor] = None,
                 image_context: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
         if not xt.is_cuda:
@@ -390,9 +410,14 @@ class ConditionalUNet(nn.Module):
         Ws = [Wp >> i for i in range(D)]
         Ms = [B * Hs[i] * Ws[i] for i in range(D)]
         sdt = pk["adt"]    # the activation stream's dtype: fp32, or bf16 in bf16 mode
+        # precise tail path (bf16 mode): the full-resolution tensors the noise prediction is a short linear map of -- the
+        # stem features and the last up conv's output (the two halves of catF), the final ResBlock's res_conv and output
+        # -- stay fp32 and that res_conv is an fp32 GEMM: a bf16 step's error against the fp32 model falls from 5.9e-3
+        # to ~3.4e-3 rel. L2 (tools/exp/sde_err_sets.py), which is what a 100-step sampling loop needs to hold 50 dB
+        tdt = f32 if (self.precise_tail or sdt == f32) else sdt
         catA = [self._buf(f"catA{i}", Ms[i], lv[i][1] + lv[i][0], sdt, dev) for i in range(D)]
         catB = [self._buf(f"catB{i}", Ms[i], lv[i][1] + lv[i][0], sdt, dev) for i in range(D)]
-        catF = self._buf("catF", Ms[0], 2 * nf, sdt, dev)
+        catF = self._buf("catF", Ms[0], 2 * nf, tdt, dev)
 
         x_in = self._buf("x_in", Ms[0], 8, f32, dev)
         ops.unet_input(xt, cond, Hp, Wp, x_in)
@@ -441,8 +466,8 @@ class ConditionalUNet(nn.Module):
                               ups=1, bias=u["b_up"])
             else:
                 ops.conv_gemm(t3, u["w_up"], catF[:, :nf], B=B, H=Hs[i], W=Ws[i], C_=dout, N=din, KH=3, KW=3, pad=1)
-        fin = self._buf("fin", Ms[0], nf, sdt, dev)
-        self._resblock(pk["final"], catF, fin, B, Hp, Wp, ss_all, "fin")
+        fin = self._buf("fin", Ms[0], nf, tdt, dev)
+        self._resblock(pk["final"], catF, fin, B, Hp, Wp, ss_all, "fin", precise_res=tdt != sdt)
         out = torch.empty(B, self.out_nc, H, W, dtype=f32, device=dev)
         ops.tail_conv3x3(fin, B, Hp, Wp, nf, pk["tail_w"], pk["tail_b"], self.out_nc, out)
         return out
