@@ -413,7 +413,7 @@ def worker(args, rank: int, world: int, dist, backend, cpu_only: bool) -> int:
         tot = shard.allreduce_metrics(acc.tolist(), "cuda")           # train_student.py:646 counterpart
         per_rank = [0] * world
         if dist is not None:
-            cts = torch.zeros(world, dtype=torch.float64, device="cuda")
+            cts = torch.zeros(world, dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
             cts[rank] = extra_cfg["images_this_rank"]
             dist.all_reduce(cts)
             per_rank = [int(v) for v in cts.tolist()]

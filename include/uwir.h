@@ -338,6 +338,12 @@ int uwir_softmax_rows(const float* x, int ldx, int B, int C, const float* mul, f
  * Cout <= 4. */
 int uwir_tail_conv3x3(const void* x, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                       int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
+/* The same conv on fp32 rows with "bf16 x 3" products on the matrix cores (same reference lines): inputs and weights are
+ * split hi + lo in the kernel, w_hi x_hi + w_lo x_hi + w_hi x_lo, i.e. each product to ~2^-16 -- the UNet's bf16 mode
+ * with the precise tail path (unet.py); uwir_tail_conv3x3 on fp32 rows stays exact fp32.  Cin 32 or 64 takes the MFMA
+ * kernel, anything else the exact one. */
+int uwir_tail_conv3x3_split(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                            int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream);
 
 /* ---- evaluation metrics of the student's eval loops, underwater_ir/student/train_student.py:70-95 ----------------
  * x, y NCHW fp32 [B,C,H,W] -> out [B,3] = per image (ssim_loss, mse, psnr): ssim_loss = mean(1 - ssim_map) with the

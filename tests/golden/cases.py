@@ -81,6 +81,15 @@ STUDENT_BIG_CASES = {
                     mask_hw=(7, 7), wseed=0, xseed=1234, taps=["head"]),
 }
 
+# 512 x 512 (BASELINE configs[4] shapes; n = 65536 tokens at level 0).  The REFERENCE cannot run this size in the build
+# container: its CFC attention materialises the (B, 4, n, n) score matrix (cfc.py:31-35), 68.7 GB in fp32 against 64 GB of
+# RAM.  These vectors are therefore ORACLE-generated (oracle/student_ref.py in fp64, which chunks the queries of both
+# attentions; the same oracle is pinned to the reference's own outputs at 256 x 256 and below): make_golden.py student_oracle
+STUDENT_ORACLE_CASES = {
+    "prod512": dict(base_channels=64, blocks_per_level=2, cond_dim=512, num_masks=10, num_deg=10, batch=1, H=512, W=512,
+                    mask_hw=(7, 7), wseed=0, xseed=99),
+}
+
 UNET_BIG_CASES = {
     # U/options/test.yml topology and width, one 256x256 sample, float time like t * sample_scale
     "prod256": dict(nf=64, ch_mult=[1, 2, 4, 8], degra=True, image=True, batch=1, H=256, W=256, times=[37.0], wseed=8,

@@ -24,8 +24,8 @@ sys.path.insert(0, "/root/reference")
 from underwater_image_restoration_amd.synth import (student_param_shapes, synth_state_dict,  # noqa: E402
                                                     synth_student_inputs)
 from underwater_image_restoration_amd.synth import daclip_vision_param_shapes, unet_param_shapes  # noqa: E402
-from tests.golden.cases import (DACLIP_CASES, STUDENT_BIG_CASES, STUDENT_CASES, UNET_BIG_CASES, UNET_CASES,  # noqa: E402
-                                compress, daclip_image, unet_inputs)
+from tests.golden.cases import (DACLIP_CASES, STUDENT_BIG_CASES, STUDENT_CASES, STUDENT_ORACLE_CASES, UNET_BIG_CASES,  # noqa: E402
+                                UNET_CASES, compress, daclip_image, unet_inputs)
 
 
 def student_case(name: str, cfg: dict) -> None:
@@ -84,6 +84,29 @@ def student_case(name: str, cfg: dict) -> None:
     np.savez_compressed(os.path.join(HERE, f"student_{name}.npz"), **store)
     print(name, "out range", float(out.min()), float(out.max()),
           "saturated frac", float(((out == 0) | (out == 1)).float().mean()))
+
+
+def student_oracle_case(name: str, cfg: dict) -> None:
+    """ORACLE-generated vectors (not the reference: see cases.STUDENT_ORACLE_CASES for why): oracle/student_ref.py in fp64.
+    Stored: the pre-clamp head output (+ input) rounded to fp32 -- the restored image is its clamp to [0, 1] -- the
+    degradation logits and the sub-sampled last alpha map."""
+    from oracle import student_ref as R
+    mk = dict(base_channels=cfg["base_channels"], num_levels=3, blocks_per_level=cfg["blocks_per_level"],
+              cond_dim=cfg["cond_dim"], num_masks=cfg["num_masks"], num_degradation_types=cfg["num_deg"])
+    sd = {k: v.double() for k, v in synth_state_dict(student_param_shapes(**mk), seed=cfg["wseed"]).items()}
+    x, z, m = synth_student_inputs(cfg["batch"], cfg["H"], cfg["W"], cfg["cond_dim"], cfg["num_masks"],
+                                   mask_hw=cfg["mask_hw"], seed=cfg["xseed"])
+    taps = {}
+    with torch.no_grad():
+        out, alphas, logits = R.student_forward(sd, x.double(), z.double(), None if m is None else m.double(),
+                                                blocks_per_level=cfg["blocks_per_level"], taps=taps)
+    pre = taps["pre_clamp"]
+    assert float((pre.clamp(0, 1) - out).abs().max()) == 0.0
+    store = {"pre_clamp_f64": pre.numpy().astype(np.float32), "logits_f64": logits.numpy(),
+             "alpha_last_f64": compress(alphas[-1]).astype(np.float64), "generated_by": np.array("oracle/student_ref.py fp64")}
+    np.savez_compressed(os.path.join(HERE, f"student_{name}.npz"), **store)
+    print(name, "out range", float(out.min()), float(out.max()),
+          "saturated frac", float(((out == 0) | (out == 1)).double().mean()))
 
 
 def dwt_case() -> None:
@@ -431,6 +454,9 @@ if __name__ == "__main__":
     if "student_big" in which:      # not in the default set: minutes of CPU time and ~25 GB of RAM (fp64 CFC scores)
         for name, cfg in STUDENT_BIG_CASES.items():
             student_case(name, cfg)
+    if "student_oracle" in which:   # 512 x 512 in fp64 through the chunked oracle: ~15 minutes, ~20 GB
+        for name, cfg in STUDENT_ORACLE_CASES.items():
+            student_oracle_case(name, cfg)
     if "unet_big" in which:
         for name, cfg in UNET_BIG_CASES.items():
             unet_case(name, cfg)

@@ -76,3 +76,30 @@ def test_launcher_deadline_kills_every_rank():
         assert time.monotonic() - t0 < 30
     finally:
         os.remove(script)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_strong_scaling_leg_on_two_ranks_sharing_the_gpu():
+    """configs[4]'s strong-scaling leg on more than one rank: `bench.py --gpus 2 --rehearse gpu --workload dataset4096`
+    started bare spawns two ranks (both on cuda:0, rendezvous over gloo), splits the image set with shard.shard_range,
+    all-reduces the metrics (train_student.py:646 counterpart) and lets rank 0 print one line."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "gpu", "--workload",
+                        "dataset4096", "--images", "8", "--dataset-size", "64", "--warmup", "1", "--gather"], env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["ranks"]["ranks_in_group"] == 2 and line["ranks"]["backend"] == "gloo"
+    assert line["config"]["images_per_rank"] == [4, 4] and line["config"]["images_total"] == 8
+    assert line["config"]["gathered_on_rank0"] == [8, 3, 64, 64]
+    m = line["dataset_metrics"]
+    assert m["images"] == 8 and 0.0 < m["mean_psnr_vs_input_db"] <= 100.0 and -1.0 <= m["mean_ssim_vs_input"] <= 1.0
+    assert line["value"] > 0

@@ -873,6 +873,51 @@ def test_flash_attn_bound_band_60_to_90(ops):
     assert not torch.equal(o_f, o_o)                                   # the two launches are different kernels
 
 
+def test_flash_attn_two_v_fallback_at_65536(ops):
+    """configs[4]'s CFC attention (cfc.py:24-39) at its production length: two V's, head_dim 16, 4 heads, n = 65536 (a 512 x 512
+    frame at level 0).  Outlier keys (one dimension at 300) defeat the norm bound for every query; the per-dimension bound
+    keeps the queries that do not use that dimension on the no-shift stream kernel, and every query of each FOURTH
+    128-query group does use it: exactly 25 % of the groups (128 of 512 per head) must fall back to the online-max
+    kernel -- bit-equal to the fast=False launch there, different from it elsewhere -- and all of it must match the
+    chunked fp64 softmax attention."""
+    from underwater_image_restoration_amd import _lib
+    lib = _lib.load()
+    b, n, heads, hd = 1, 65536, 4, 16
+    assert lib.uwir_flash_attn_packed_workspace_bytes(b, n, heads, hd, 2) > lib.uwir_flash_attn_workspace_bytes(b, n, heads) + n * heads * hd
+    g = torch.Generator().manual_seed(65)
+    wdt = heads * hd
+    c = 1.4426950408889634 / math.sqrt(hd)
+    q = torch.randn(n, heads, hd, generator=g)
+    k = torch.randn(n, heads, hd, generator=g)
+    q[:, :, 0] = 0.0
+    k[torch.randperm(n, generator=g)[:40], :, 0] = 300.0      # outlier keys
+    hot = (torch.arange(n) // 128) % 4 == 1                    # every fourth 128-query group
+    q[hot, :, 0] = 6.0                                         # scores up to 6 * 300 / 4 * log2(e) ~ 650 there
+    q, k = q.reshape(n, wdt).bfloat16().cuda(), k.reshape(n, wdt).bfloat16().cuda()
+    vt, vf = torch.randn(n, wdt, generator=g).bfloat16().cuda(), torch.randn(n, wdt, generator=g).bfloat16().cuda()
+    assert float((q.float().reshape(n, heads, hd).norm(dim=-1) * c).min()) * 300.0 > 90.0   # the norm bound rejects everything
+    refs = [torch.empty(n, wdt, dtype=torch.float64, device="cuda") for _ in range(2)]
+    for h in range(heads):
+        cols = slice(h * hd, (h + 1) * hd)
+        kk = k[:, cols].double()
+        for r0 in range(0, n, 2048):
+            a = torch.softmax(q[r0:r0 + 2048, cols].double() @ kk.T / math.sqrt(hd), dim=-1)
+            refs[0][r0:r0 + 2048, cols] = a @ vt[:, cols].double()
+            refs[1][r0:r0 + 2048, cols] = a @ vf[:, cols].double()
+    o = [torch.empty(n, wdt, device="cuda") for _ in range(2)]
+    r = [torch.empty(n, wdt, device="cuda") for _ in range(2)]
+    ops.flash_attn(q, k, vt, vf, b, n, heads, hd, 1.0 / math.sqrt(hd), o[0], o[1])
+    ops.flash_attn(q, k, vt, vf, b, n, heads, hd, 1.0 / math.sqrt(hd), r[0], r[1], fast=False)
+    torch.cuda.synchronize()
+    hot = hot.cuda()
+    for got, onl, ref in zip(o, r, refs):
+        assert bool(torch.isfinite(got).all())
+        assert err(got, ref) < 3e-2 and err(onl, ref) < 3e-2
+        assert torch.equal(got[hot], onl[hot])                 # the marked groups were redone by the online-max kernel
+        same_rows = (got[~hot] == onl[~hot]).all(dim=1).float().mean()
+        assert float(same_rows) < 0.01                         # the other 75 % came from the stream kernel
+
+
 def test_affine_cast(ops):
     g = torch.Generator().manual_seed(20)
     b, n, c = 3, 37, 24
@@ -1041,6 +1086,64 @@ def test_unet_stem_7x7_mfma(ops):
     ops.conv_gemm(to_rows(x), wd, o32, B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
     assert rel(from_rows(o32, b, h, w), ref) < 1e-4
     assert float((out[:, n:].float() - o32).abs().max()) < 0.05
+
+
+def test_precise_tail_path_variants(ops):
+    """The kernels behind the UNet's precise tail path (bf16 mode, unet.precise_tail): the 7x7 stem MFMA kernel writing
+    fp32 rows, the resident-weight 3x3 conv (C = 64, bf16 rows) with an fp32 residual and fp32 / bf16 output, and the tail
+    conv on fp32 rows (inputs and weights split hi + lo in the kernel: products to ~2^-16)."""
+    g = torch.Generator().manual_seed(93)
+    bf = torch.bfloat16
+    # stem -> fp32 rows in a column slice (the stem half of the UNet's catF)
+    b, h, w, n = 2, 40, 50, 64
+    x = torch.randn(b, 8, h, w, generator=g)
+    x[:, 6:] = 0
+    wt = torch.randn(n, 8, 7, 7, generator=g) / math.sqrt(49 * 6)
+    wd = wt.permute(0, 2, 3, 1).reshape(n, -1).bfloat16().cuda().contiguous()
+    out = torch.full((b * h * w, 2 * n), 3.0, device="cuda")
+    ops.conv_gemm(to_rows(x), wd, out[:, n:], B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
+    ref = F.conv2d(x.bfloat16().double(), wt.bfloat16().double(), padding=3)
+    assert rel(from_rows(out[:, n:], b, h, w), ref) < 1e-5 and float(out[:, :n].min()) == 3.0
+    o16 = torch.empty(b * h * w, n, device="cuda", dtype=bf)
+    ops.conv_gemm(to_rows(x), wd, o16, B=b, H=h, W=w, C_=8, N=n, KH=7, KW=7, pad=3)
+    assert torch.equal(o16, out[:, n:].to(bf))                  # same accumulators, rounded at the store
+    # resident-weight conv (C = 64 bf16 rows): fp32 residual, per-sample scale / bias, SiLU, fp32 and bf16 rows out
+    bb, c, hh, ww = 3, 64, 40, 52
+    xi = to_rows(torch.randn(bb, c, hh, ww, generator=g)).to(bf)
+    wc = torch.randn(64, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    res32 = torch.randn(bb * hh * ww, 64 + 8, generator=g).cuda()
+    sc, sh = (torch.rand(bb, 64, generator=g) + 0.5).cuda(), torch.randn(bb, 64, generator=g).cuda()
+    xe = xi.float().cpu().reshape(bb, hh, ww, c).permute(0, 3, 1, 2).double()
+    refc = F.conv2d(xe, wc.bfloat16().double(), padding=1) * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    refc = F.silu(refc) + from_rows(res32[:, :64].double(), bb, hh, ww).cpu()
+    wcd = wc.permute(0, 2, 3, 1).reshape(64, -1).bfloat16().cuda().contiguous()
+    outs = {}
+    for odt in (torch.float32, bf):
+        o = torch.empty(bb * hh * ww, 64, device="cuda", dtype=odt)
+        ops.conv_gemm(xi, wcd, o, B=bb, H=hh, W=ww, C_=c, N=64, KH=3, KW=3, pad=1, act=ops.ACT_SILU, res=res32[:, :64],
+                      batch_scale=sc, batch_bias=sh)
+        assert rel(from_rows(o, bb, hh, ww), refc) < (1e-5 if odt == torch.float32 else 1e-2), odt
+        outs[odt] = o
+    from underwater_image_restoration_amd import _lib
+    _lib.load().uwir_conv_variant(1 << 3)                      # LDS-DMA convs off: the register-staged kernel must agree
+    try:
+        o = torch.empty(bb * hh * ww, 64, device="cuda")
+        ops.conv_gemm(xi, wcd, o, B=bb, H=hh, W=ww, C_=c, N=64, KH=3, KW=3, pad=1, act=ops.ACT_SILU, res=res32[:, :64],
+                      batch_scale=sc, batch_bias=sh)
+    finally:
+        _lib.load().uwir_conv_variant(0)
+    assert float((o - outs[torch.float32]).abs().max()) < 1e-4
+    # tail conv on fp32 rows: MFMA with hi + lo splits of both operands, against fp64 on the UNROUNDED operands
+    for cin, h2, w2, co in ((64, 40, 50, 3), (32, 16, 32, 4)):
+        feat = torch.randn(2, cin, h2, w2, generator=g) * 2
+        wt3, bt3 = torch.randn(co, cin, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
+        rows = torch.full((2 * h2 * w2, cin + 8), 9.0, device="cuda")
+        rows[:, :cin] = to_rows(feat)
+        o = torch.empty(2, co, h2 - 3, w2 - 1, device="cuda")
+        ops.tail_conv3x3(rows[:, :cin], 2, h2, w2, cin, wt3.permute(0, 2, 3, 1).contiguous().cuda(), bt3.cuda(), co, o, split=True)
+        refd = F.conv2d(feat.double(), wt3.double(), bt3.double(), padding=1)[..., :h2 - 3, :w2 - 1]
+        e = rel(o, refd)
+        assert e < 5e-5, (cin, e)                                # relative to max |out|; plain bf16 operands give ~4e-3
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -1013,8 +1013,10 @@ extern "C" int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nw
 // MFMAs per fragment: 16 mantissa bits, the last layer's weights are not rounded to bf16), staged once per block in LDS in
 // fragment order; the activation fragments are 16-byte global loads (pixel (y + ky - 1, x + kx - 1), 8 channels), zero
 // outside the image.  A wave walks 8 rows of a 16-pixel column strip; lanes 0-15 hold the pixel's channels 0-3.
-template <int NCH>
-__global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict__ x, int ldx, int H, int W,
+// fp32 rows (TX = float: the precise tail path of the UNet's bf16 mode): each 8-channel piece is split into hi + lo bf16
+// fragments in registers and takes three MFMAs (w_hi x_hi + w_lo x_hi + w_hi x_lo: the product to ~2^-16).
+template <int NCH, typename TX>
+__global__ void __launch_bounds__(256) tail_mfma_kernel(const TX* __restrict__ x, int ldx, int H, int W,
                                                         const float* __restrict__ w, const float* __restrict__ bias, int Cout,
                                                         float* __restrict__ out, int Ho, int Wo) {
     constexpr int NF = 9 * NCH, Cin = 32 * NCH;
@@ -1041,29 +1043,46 @@ __global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict
     }
     __syncthreads();
     const int b = blockIdx.z, px = blockIdx.x * 16 + fr, ybase = blockIdx.y * 32 + wave * 8;
-    const bf16_t* xb = x + (size_t)b * H * W * ldx + fq * 8;
+    constexpr bool X32 = sizeof(TX) == 4;
+    constexpr int NR = X32 ? 2 : 1;                                  // fragments per piece: hi (+ lo)
+    const TX* xb = x + (size_t)b * H * W * ldx + fq * 8;
     float bv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = (bias && e < Cout) ? bias[e] : 0.f;
     // rolling window over the input rows: fragments of rows y - 1, y, y + 1 are live, each new output row loads one row
-    auto load_row = [&](int iy, bf16x8 (&dst)[3 * NCH]) {
+    auto load_row = [&](int iy, bf16x8 (&dst)[3 * NCH * NR]) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = px + kx - 1;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const bf16_t* src = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ldx;
+            const TX* src = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c * 32);
-                if (!ok) {
+                if constexpr (X32) {
+                    const float4 a0 = load4(src + c * 32), a1 = load4(src + c * 32 + 4);
+                    const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    bf16x8 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = ok ? f[j] : 0.f;
+                        const bf16_t h = (bf16_t)v;
+                        hi[j] = h;
+                        lo[j] = (bf16_t)(v - (float)h);
+                    }
+                    dst[(kx * NCH + c) * 2] = hi;
+                    dst[(kx * NCH + c) * 2 + 1] = lo;
+                } else {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c * 32);
+                    if (!ok) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+                    }
+                    dst[kx * NCH + c] = v;
                 }
-                dst[kx * NCH + c] = v;
             }
         }
     };
-    bf16x8 rows[3][3 * NCH];
+    bf16x8 rows[3][3 * NCH * NR];
     load_row(ybase - 1, rows[0]);
     load_row(ybase, rows[1]);
 #pragma unroll
@@ -1071,7 +1090,7 @@ __global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict
         const int y = ybase + r;
         if (y < Ho) {                                               // wave-uniform
             load_row(y + 1, rows[(r + 2) % 3]);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: hi and lo weights
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: hi weights; the small terms
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1079,8 +1098,10 @@ __global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict
                     const int f = ky * 3 * NCH + t;                 // fragment = (ky * 3 + kx) * NCH + c
                     const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)(f * 64 + lane) * 8]);
                     const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)((NF + f) * 64 + lane) * 8]);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rows[(r + ky) % 3][t], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, rows[(r + ky) % 3][t], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rows[(r + ky) % 3][t * NR], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, rows[(r + ky) % 3][t * NR], acc1, 0, 0, 0);
+                    if constexpr (X32)
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rows[(r + ky) % 3][t * NR + 1], acc1, 0, 0, 0);
                 }
             if (fq == 0 && px < Wo) {
 #pragma unroll
@@ -1091,23 +1112,29 @@ __global__ void __launch_bounds__(256) tail_mfma_kernel(const bf16_t* __restrict
     }
 }
 
-extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w,
-                                 const float* bias, int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
+static int tail_conv3x3_impl(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w,
+                             const float* bias, int Cout, float* out_nchw, int Ho, int Wo, bool split, uwir_stream_t stream) {
     UWIR_CHECK(xv && w && out_nchw, "tail: null pointer");
     UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "tail: bad input dtype");
     const float* x = (const float*)xv;
     UWIR_CHECK(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout >= 1 && Cout <= HEAD_MAX_COUT && ldx >= Cin &&
                    ldx % 4 == 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W,
                "tail: bad shape (Cout<=%d, crop within the map)", HEAD_MAX_COUT);
-    if (x_dtype == UWIR_BF16 && (Cin == 32 || Cin == 64) && ldx % 8 == 0 && (((uintptr_t)xv | (uintptr_t)w) & 15) == 0 && B <= 65535 &&
-        ceil_div(Ho, 32) <= 65535) {
+    if ((x_dtype == UWIR_BF16 || split) && (Cin == 32 || Cin == 64) && ldx % 8 == 0 && (((uintptr_t)xv | (uintptr_t)w) & 15) == 0 &&
+        B <= 65535 && ceil_div(Ho, 32) <= 65535) {
         const dim3 grid(ceil_div(Wo, 16), ceil_div(Ho, 32), B);
-        if (Cin == 64)
-            hipLaunchKernelGGL(tail_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w, bias,
-                               Cout, out_nchw, Ho, Wo);
+        if (x_dtype == UWIR_BF16 && Cin == 64)
+            hipLaunchKernelGGL((tail_mfma_kernel<2, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w,
+                               bias, Cout, out_nchw, Ho, Wo);
+        else if (x_dtype == UWIR_BF16)
+            hipLaunchKernelGGL((tail_mfma_kernel<1, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w,
+                               bias, Cout, out_nchw, Ho, Wo);
+        else if (Cin == 64)
+            hipLaunchKernelGGL((tail_mfma_kernel<2, float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)xv, ldx, H, W, w,
+                               bias, Cout, out_nchw, Ho, Wo);
         else
-            hipLaunchKernelGGL(tail_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W, w, bias,
-                               Cout, out_nchw, Ho, Wo);
+            hipLaunchKernelGGL((tail_mfma_kernel<1, float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)xv, ldx, H, W, w,
+                               bias, Cout, out_nchw, Ho, Wo);
         UWIR_LAUNCH_CHECK("tail(mfma)");
         return UWIR_OK;
     }
@@ -1133,6 +1160,16 @@ extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
                        (float*)nullptr, Ho, Wo, 0);
     UWIR_LAUNCH_CHECK("tail");
     return UWIR_OK;
+}
+
+extern "C" int uwir_tail_conv3x3(const void* xv, int x_dtype, int ldx, int B, int H, int W, int Cin, const float* w,
+                                 const float* bias, int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
+    return tail_conv3x3_impl(xv, x_dtype, ldx, B, H, W, Cin, w, bias, Cout, out_nchw, Ho, Wo, false, stream);
+}
+
+extern "C" int uwir_tail_conv3x3_split(const float* x, int ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                                       int Cout, float* out_nchw, int Ho, int Wo, uwir_stream_t stream) {
+    return tail_conv3x3_impl(x, UWIR_F32, ldx, B, H, W, Cin, w, bias, Cout, out_nchw, Ho, Wo, true, stream);
 }
 
 // ------------------------------------------------------------------------------------------

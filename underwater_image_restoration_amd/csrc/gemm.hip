@@ -1180,7 +1180,7 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
 // vmcnt(0) at the END of the chunk's MFMAs, BEFORE the epilogue issues its stores (loads and stores share vmcnt and
 // complete out of order between them: a counted wait with stores in flight proves nothing).
 // ------------------------------------------------------------------------------------------
-template <int NCH>   // 32-channel chunks per tile: C = 32 * NCH
+template <int NCH, bool RES32 = false>   // 32-channel chunks per tile: C = 32 * NCH; RES32: the residual rows are fp32
 __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
     constexpr int BN = 64, TH = 8, TM = 2, TN = 4, NB = 3;         // NB halo buffers per group: DMA runs two chunks ahead
     constexpr int A_PIECES = ((TH + 2) * CD_PWL + 15) / 16;        // 13 wave-instructions of 16 LDS rows (the last is partial)
@@ -1319,6 +1319,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
     const int nq0 = n0 + fq * 16;                                  // this lane's 16 channels: nq0 + j * 4 .. + 3
     f32x4 e_bias[TN], e_bs[TN], e_bb[TN];
     uint2 e_res[TM][TN];
+    f32x4 e_res32[RES32 ? TM : 1][TN];
     long long e_row[TM];                                           // output row of (tile row i, pixel fr), or -1
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -1341,9 +1342,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
             const bool ok = oy < OH && ox < OW;
             e_row[i] = ok ? ((long long)tc.b * OH + oy) * OW + ox : -1;
             if (e_resp) {
-                const bf16_t* rp = (const bf16_t*)e_resp + (size_t)(ok ? e_row[i] : 0) * g.ldr + nq0;
+                if constexpr (RES32) {
+                    const float* rp = (const float*)e_resp + (size_t)(ok ? e_row[i] : 0) * g.ldr + nq0;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) e_res[i][j] = *reinterpret_cast<const uint2*>(rp + j * 4);
+                    for (int j = 0; j < TN; ++j) e_res32[i][j] = *reinterpret_cast<const f32x4*>(rp + j * 4);
+                } else {
+                    const bf16_t* rp = (const bf16_t*)e_resp + (size_t)(ok ? e_row[i] : 0) * g.ldr + nq0;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) e_res[i][j] = *reinterpret_cast<const uint2*>(rp + j * 4);
+                }
             }
         }
     };
@@ -1361,11 +1368,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
                     for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * sigmoid_fast(v[j][e]);
                 }
                 if (e_resp) {
-                    const unsigned lo = e_res[i][j].x, hi = e_res[i][j].y;
-                    v[j][0] += __uint_as_float(lo << 16);
-                    v[j][1] += __uint_as_float(lo & 0xffff0000u);
-                    v[j][2] += __uint_as_float(hi << 16);
-                    v[j][3] += __uint_as_float(hi & 0xffff0000u);
+                    if constexpr (RES32) {
+                        v[j] += e_res32[i][j];
+                    } else {
+                        const unsigned lo = e_res[i][j].x, hi = e_res[i][j].y;
+                        v[j][0] += __uint_as_float(lo << 16);
+                        v[j][1] += __uint_as_float(lo & 0xffff0000u);
+                        v[j][2] += __uint_as_float(hi << 16);
+                        v[j][3] += __uint_as_float(hi & 0xffff0000u);
+                    }
                 }
             }
             if (e_row[i] < 0) continue;
@@ -1433,8 +1444,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
 // fragment piece is exactly ONE input pixel -- the 56 weight fragments live in LDS in fragment order, and a wave walks 8
 // output rows of a 16-pixel column strip with a rolling window of 7 input rows in registers (2 fragment loads per new row).
 // ------------------------------------------------------------------------------------------
+template <typename TO>   // bf16 rows, or fp32 rows (the precise tail path of the UNet's bf16 mode keeps the stem features fp32)
 __global__ void __launch_bounds__(256) stem7_mfma_kernel(const float* __restrict__ x, int lda, int H, int W,
-                                                         const bf16_t* __restrict__ wt, bf16_t* __restrict__ out, int ldo) {
+                                                         const bf16_t* __restrict__ wt, TO* __restrict__ out, int ldo) {
     constexpr int NF = 7 * 2 * 4;                                  // fragments: (ky, k-step s, channel tile j)
     __shared__ __attribute__((aligned(16))) bf16_t s_w[NF * 64 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -1485,13 +1497,18 @@ __global__ void __launch_bounds__(256) stem7_mfma_kernel(const float* __restrict
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, rows[(r + ky) % 7][s2], acc[j], 0, 0, 0);
                     }
             if (x0 + fr < W) {
-                bf16_t* op = out + ((size_t)(b * H + y) * W + x0 + fr) * ldo + fq * 16;
+                TO* op = out + ((size_t)(b * H + y) * W + x0 + fr) * ldo + fq * 16;
+                if constexpr (sizeof(TO) == 2) {
 #pragma unroll
-                for (int jp = 0; jp < 4; jp += 2) {
-                    bf16x8 o;
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)acc[jp][e]; o[4 + e] = (bf16_t)acc[jp + 1][e]; }
-                    *reinterpret_cast<bf16x8*>(op + jp * 4) = o;
+                        for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)acc[jp][e]; o[4 + e] = (bf16_t)acc[jp + 1][e]; }
+                        *reinterpret_cast<bf16x8*>(op + jp * 4) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(op + j * 4) = acc[j];
                 }
             }
         }
@@ -1502,7 +1519,8 @@ static bool stem7_eligible(const uwir_gemm_args& g) {
     return g.compute == UWIR_BF16 && g.KH == 7 && g.KW == 7 && g.stride == 1 && g.pad == 3 && g.C == 8 && g.N == 64 &&
            g.a_dtype == UWIR_F32 && g.lda % 4 == 0 && g.ups == 0 && g.OH == g.H && g.OW == g.W && !g.a_scale && !g.bias &&
            !g.batch_bias && !g.batch_scale && g.act == UWIR_ACT_NONE && !g.res && !g.col_scale && !g.blend_out &&
-           g.store_mode == 0 && g.out && g.out_dtype == UWIR_BF16 && g.ldo % 8 == 0 && ((uintptr_t)g.out & 15) == 0 &&
+           g.store_mode == 0 && g.out && (g.out_dtype == UWIR_BF16 || g.out_dtype == UWIR_F32) && g.ldo % 8 == 0 &&
+           ((uintptr_t)g.out & 15) == 0 &&
            ((uintptr_t)g.A & 15) == 0 && g.B <= 65535 && ceil_div(g.H, 32) <= 65535;
 }
 
@@ -1557,7 +1575,7 @@ static int launch_conv_dma(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
     const uwir_gemm_args& ga = p.a;
     const bool resw_epi = (ga.act == UWIR_ACT_NONE || ga.act == UWIR_ACT_SILU) && !ga.col_scale && !ga.blend_out && ga.store_mode == 0 && !ga.res_scale && ga.out &&
-                          (!ga.res || (ga.res_dtype == UWIR_BF16 && ga.ldr % 4 == 0)) &&
+                          (!ga.res || ((ga.res_dtype == UWIR_BF16 || ga.res_dtype == UWIR_F32) && ga.ldr % 4 == 0)) &&
                           ((uintptr_t)ga.out & 15) == 0 && ga.ldo % 8 == 0 &&
                           (((uintptr_t)ga.bias | (uintptr_t)ga.batch_scale | (uintptr_t)ga.batch_bias) & 15) == 0;
     if (p.a.C == 64 && g_conv_dma != 7 && resw_epi) {   // short K: persistent blocks with the weight slice resident in LDS
@@ -1567,7 +1585,10 @@ static int launch_conv_dma(const GemmP& p0, hipStream_t stream) {
         if (nmblk < 1) nmblk = 1;
         if (nmblk > (mtiles + 1) / 2) nmblk = (mtiles + 1) / 2;
         p.nblocks = (int)(nmblk * p.tiles_n);
-        hipLaunchKernelGGL((conv3x3_resw_kernel<2>), dim3(p.nblocks), dim3(512), 0, stream, p);
+        if (ga.res && ga.res_dtype == UWIR_F32)
+            hipLaunchKernelGGL((conv3x3_resw_kernel<2, true>), dim3(p.nblocks), dim3(512), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv3x3_resw_kernel<2, false>), dim3(p.nblocks), dim3(512), 0, stream, p);
         UWIR_LAUNCH_CHECK("conv_gemm(resident weights)");
         return UWIR_OK;
     }
@@ -1730,8 +1751,12 @@ extern "C" int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream) 
     p.splitk = 1;
     hipStream_t s = (hipStream_t)stream;
     if (stem7_eligible(g)) {
-        hipLaunchKernelGGL(stem7_mfma_kernel, dim3(ceil_div(g.W, 16), ceil_div(g.H, 32), g.B), dim3(256), 0, s,
-                           (const float*)g.A, g.lda, g.H, g.W, (const bf16_t*)g.Wt, (bf16_t*)g.out, g.ldo);
+        if (g.out_dtype == UWIR_BF16)
+            hipLaunchKernelGGL(stem7_mfma_kernel<bf16_t>, dim3(ceil_div(g.W, 16), ceil_div(g.H, 32), g.B), dim3(256), 0, s,
+                               (const float*)g.A, g.lda, g.H, g.W, (const bf16_t*)g.Wt, (bf16_t*)g.out, g.ldo);
+        else
+            hipLaunchKernelGGL(stem7_mfma_kernel<float>, dim3(ceil_div(g.W, 16), ceil_div(g.H, 32), g.B), dim3(256), 0, s,
+                               (const float*)g.A, g.lda, g.H, g.W, (const bf16_t*)g.Wt, (float*)g.out, g.ldo);
         UWIR_LAUNCH_CHECK("conv_gemm(stem 7x7)");
         return UWIR_OK;
     }

@@ -474,10 +474,16 @@ def softmax_rows(x: torch.Tensor, mul, y: torch.Tensor) -> None:
     _lib.check(lib.uwir_softmax_rows(_p(x), _ld(x), B, C_, _p(mul), _p(y), _ld(y), _stream(x)), "softmax_rows")
 
 
-def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cout: int, out_nchw: torch.Tensor) -> None:
+def tail_conv3x3(x: torch.Tensor, B: int, H: int, W: int, Cin: int, w, bias, Cout: int, out_nchw: torch.Tensor,
+                 split: bool = False) -> None:
+    """``split`` (fp32 rows only): bf16 x 3 products on the matrix cores instead of exact fp32 (uwir_tail_conv3x3_split)."""
     _f32(w, bias, out_nchw)
     lib = _lib.load()
     Ho, Wo = out_nchw.shape[2], out_nchw.shape[3]
+    if split and x.dtype == torch.float32:
+        _lib.check(lib.uwir_tail_conv3x3_split(_p(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo,
+                                               _stream(x)), "tail_conv3x3_split")
+        return
     _lib.check(lib.uwir_tail_conv3x3(_p(x), _dt(x), _ld(x), B, H, W, Cin, _p(w), _p(bias), Cout, _p(out_nchw), Ho, Wo, _stream(x)),
                "tail_conv3x3")
 

@@ -45,6 +45,9 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[tor
     rank, ws = world()
     if ws == 1:
         return local
+    if local.is_cuda and dist.get_backend() == "gloo":      # rehearsals: gloo moves host memory
+        out = gather_rows(local.cpu(), n_total, dst)
+        return None if out is None else out.to(local.device)
     per = math.ceil(n_total / ws)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
@@ -62,6 +65,8 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[tor
 def allreduce_metrics(values: Sequence[float], device) -> List[float]:
     """SUM all-reduce of a small fp64 vector, e.g. [psnr_sum, ssim_sum, count] (train_student.py:646 uses AVG of one
     scalar; sums + count give exact dataset means for ragged shards)."""
+    if world()[1] > 1 and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     if world()[1] > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -106,6 +111,10 @@ def restore_frame_sharded(restorer, x: torch.Tensor, cond: torch.Tensor, masks: 
         desc = restorer.window_descriptors(x.shape[0], tiles, x.device, (H, W)).view(x.shape[0], len(tiles), 8)[:, lo:hi]
         if hi > lo:
             restorer.restore_windows_inplace(x, cond, fm, desc.reshape(-1, 8).contiguous(), local)
+        if dist.get_backend() == "gloo":                   # rehearsals: gloo moves host memory
+            host = local.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            return host.to(x.device) if rank == dst else None
         dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM)
         return local if rank == dst else None
     T = restorer.tile

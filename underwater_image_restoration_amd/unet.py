@@ -469,7 +469,7 @@ class ConditionalUNet(nn.Module):
         fin = self._buf("fin", Ms[0], nf, tdt, dev)
         self._resblock(pk["final"], catF, fin, B, Hp, Wp, ss_all, "fin", precise_res=tdt != sdt)
         out = torch.empty(B, self.out_nc, H, W, dtype=f32, device=dev)
-        ops.tail_conv3x3(fin, B, Hp, Wp, nf, pk["tail_w"], pk["tail_b"], self.out_nc, out)
+        ops.tail_conv3x3(fin, B, Hp, Wp, nf, pk["tail_w"], pk["tail_b"], self.out_nc, out, split=tdt != sdt)
         return out
 
     @staticmethod
