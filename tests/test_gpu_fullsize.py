@@ -63,7 +63,7 @@ def test_configs1_batch16_256_properties(student):
 
 
 def test_configs2_1080p_tiling_invariants(student):
-    """configs[2]: one 1920x1080 frame through 60 halo windows; the stitched frame must not depend on how the windows
+    """configs[2]: one 1920x1080 frame through its 45 halo windows (the default 16-px halo); the stitched frame must not depend on how the windows
     are batched, and every owned pixel is written exactly once (a constant frame stays inside [0, 1] and finite)."""
     from underwater_image_restoration_amd.tiling import TiledRestorer
     model, _ = student
@@ -71,15 +71,15 @@ def test_configs2_1080p_tiling_invariants(student):
     frame = torch.rand(1, 3, 1080, 1920, generator=g).cuda()
     z = torch.randn(1, 512, generator=g).cuda()
     m = torch.rand(1, 10, 7, 7, generator=g).cuda()
-    a = TiledRestorer(model, tile=256, halo=32, max_batch=30)(frame, z, m)
-    b = TiledRestorer(model, tile=256, halo=32, max_batch=7)(frame, z, m)
+    a = TiledRestorer(model, max_batch=45)(frame, z, m)
+    b = TiledRestorer(model, max_batch=7)(frame, z, m)
     assert a.shape == frame.shape and bool(torch.isfinite(a).all())
     assert psnr(a, b) > 60.0
     assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
     # configs[2] names fp32 as well: the same frame through the exact-fp32 path, and bf16 against it
     model.set_precision("fp32")
     try:
-        f32 = TiledRestorer(model, tile=256, halo=32, max_batch=30)(frame, z, m)
+        f32 = TiledRestorer(model, max_batch=23)(frame, z, m)
     finally:
         model.set_precision("bf16")
     assert bool(torch.isfinite(f32).all()) and float(f32.min()) >= 0.0 and float(f32.max()) <= 1.0
