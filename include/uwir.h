@@ -95,6 +95,14 @@ int uwir_ln2d_affine_noalloc(const void* x, int x_dtype, int ldx, int B, int n, 
 int uwir_affine_cast(const void* x, int x_dtype, int ldx, int B, int n, int C, const float* a, const float* s, void* out,
                      int out_dtype, int ldo, uwir_stream_t stream);
 
+/* ---- the same norm folded into the NEXT 1x1 conv's weights (S/utils.py:18-36 feeding S/wtb.py:50,71):
+ *   W (a_b x + s_b) + bias = (W diag(a_b)) x + (W s_b + bias)
+ * W fp32 [N, K] -> Wb bf16 [B, N, K] (per-image weight panels, see uwir_gemm_args.w_batch_stride), bb fp32 [B, N] (per-image
+ * bias rows, bias may be NULL); a, s fp32 [B, K] as written by uwir_ln2d_affine.  K % 8 == 0.  With it the consumer GEMM
+ * reads the un-normalised rows and uwir_affine_cast's round trip of the activation disappears. */
+int uwir_fold_affine_weights(const float* W, int N, int K, int B, const float* a, const float* s, const float* bias, void* Wb,
+                             float* bb, uwir_stream_t stream);
+
 /* ---- S/wtb.py:13-28,118-119 ChannelAttention folded into the residual ------------------------
  * With xn = a*x + s (the affine above) and w = sigmoid(MLP(mean(xn))) [B,C]:
  *   x + xn*w == x*(1 + a*w) + s*w   ->  out_scale = 1 + a*w, out_shift = s*w   (count = B*C).
@@ -159,6 +167,10 @@ typedef struct uwir_gemm_args {
     size_t workspace_bytes;
     int res_dtype;            /* dtype of res: UWIR_F32 (0, the default) or UWIR_BF16 (the IR-SDE UNet's bf16 activation
                                  stream); an affine residual (res_scale) and the lean epilogue classes take fp32 rows */
+    long long w_batch_stride; /* 0: one weight matrix.  > 0 (elements): image b multiplies by Wt + b * w_batch_stride (the
+                                 panels of uwir_fold_affine_weights).  Plain bf16 1x1 GEMMs only (bf16 rows, K % 64 == 0,
+                                 N > 64) and OH * OW % 128 == 0 (a 128-row tile never straddles two images); anything else
+                                 is rejected with UWIR_EUNSUPPORTED */
 } uwir_gemm_args;
 size_t uwir_conv_gemm_workspace_bytes(const uwir_gemm_args* args); /* 0 when the launch would not use one */
 int uwir_conv_gemm(const uwir_gemm_args* args, uwir_stream_t stream);

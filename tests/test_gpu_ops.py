@@ -1088,6 +1088,33 @@ def test_unet_stem_7x7_mfma(ops):
     assert float((out[:, n:].float() - o32).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 192, 576), (2, 128, 64, 128), (16, 1024, 768, 1536)])
+def test_fold_affine_weights_and_batched_gemm(ops, shape):
+    """LayerNorm2d's per-image affine folded into the next 1x1 conv (S/utils.py:18-36 -> S/wtb.py:50,71):
+    W (a_b x + s_b) + bias == (W diag(a_b)) x + (W s_b + bias), with per-image bf16 weight panels in the LDS-DMA GEMM."""
+    b, n, k, nn = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(b * n, k, generator=g).bfloat16()
+    W = torch.randn(nn, k, generator=g) / math.sqrt(k)
+    bias = torch.randn(nn, generator=g)
+    a, s = torch.rand(b, k, generator=g) + 0.5, torch.randn(b, k, generator=g)
+    Wb = torch.empty(b, nn, k, device="cuda", dtype=torch.bfloat16)
+    bb = torch.empty(b, nn, device="cuda")
+    ops.fold_affine_weights(W.cuda(), a.cuda(), s.cuda(), bias.cuda(), Wb, bb)
+    assert err(Wb, W.double()[None] * a.double()[:, None, :]) < 2e-2            # bf16 rounding of O(1) entries
+    assert err(bb, s.double() @ W.double().T + bias.double()) < 1e-4
+    out = torch.empty(b * n, nn, device="cuda", dtype=torch.bfloat16)
+    ops.conv_gemm(x.cuda(), Wb, out, B=b, H=n // 16, W=16, C_=k, N=nn, batch_bias=bb, act=ops.ACT_GELU, w_batched=True)
+    xn = x.double().reshape(b, n, k) * a.double()[:, None] + s.double()[:, None]
+    ref = F.gelu(xn @ W.double().T + bias.double())
+    assert rel(out.reshape(b, n, nn), ref) < 1e-2
+    # exact restatement on the bf16 panels: only the accumulation order and the output rounding remain
+    ref2 = F.gelu(torch.einsum("bnk,bok->bno", x.double().reshape(b, n, k), Wb.double().cpu()) + bb.double().cpu()[:, None])
+    assert rel(out.reshape(b, n, nn), ref2) < 5e-3
+    with pytest.raises(Exception):      # tiles would straddle images
+        ops.conv_gemm(x.cuda()[:b * 96], Wb, out[:b * 96], B=b, H=6, W=16, C_=k, N=nn, batch_bias=bb, w_batched=True)
+
+
 def test_precise_tail_path_variants(ops):
     """The kernels behind the UNet's precise tail path (bf16 mode, unet.precise_tail): the 7x7 stem MFMA kernel writing
     fp32 rows, the resident-weight 3x3 conv (C = 64, bf16 rows) with an fp32 residual and fp32 / bf16 output, and the tail

@@ -374,6 +374,53 @@ extern "C" int uwir_affine_cast(const void* x, int x_dtype, int ldx, int B, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// The per-sample affine of LayerNorm2d / AdaLayerNorm2d (S/utils.py:18-36) folded into the NEXT 1x1 conv's weights:
+//   W (a_b * x + s_b) + bias = (W diag(a_b)) x + (W s_b + bias)
+// -> one bf16 weight panel Wb[b] = W * a_b (column-wise) and one bias row bb[b] = W s_b + bias per image, so the GEMM reads
+// the un-normalised rows directly (LDS-DMA path) and no normalised copy of the activation is written or read.
+// One block per (b, 4 output rows): thread = 4-column piece; the bias row is a block reduction in fp32.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_affine_weights_kernel(const float* __restrict__ W, int N, int K,
+                                                                  const float* __restrict__ a, const float* __restrict__ s,
+                                                                  const float* __restrict__ bias, bf16_t* __restrict__ Wb,
+                                                                  float* __restrict__ bb) {
+    const int b = blockIdx.y, n0 = blockIdx.x * 4, tid = threadIdx.x;
+    __shared__ float red[4][4];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k4 = tid; k4 < K / 4; k4 += 256) {
+        const float4 a4 = load4(a + (size_t)b * K + 4 * k4), s4 = load4(s + (size_t)b * K + 4 * k4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n0 + r < N) {
+                const float4 w4 = load4(W + (size_t)(n0 + r) * K + 4 * k4);
+                store4(Wb + ((size_t)b * N + n0 + r) * K + 4 * k4, make_float4(w4.x * a4.x, w4.y * a4.y, w4.z * a4.z, w4.w * a4.w));
+                part[r] += w4.x * s4.x + w4.y * s4.y + w4.z * s4.z + w4.w * s4.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = part[r];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[r][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 4 && n0 + tid < N)
+        bb[(size_t)b * N + n0 + tid] = ((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3])) + (bias ? bias[n0 + tid] : 0.f);
+}
+
+extern "C" int uwir_fold_affine_weights(const float* W, int N, int K, int B, const float* a, const float* s, const float* bias,
+                                        void* Wb, float* bb, uwir_stream_t stream) {
+    UWIR_CHECK(W && a && s && Wb && bb, "fold_affine_weights: null pointer");
+    UWIR_CHECK(N > 0 && K > 0 && K % 8 == 0 && B > 0 && B <= 65535, "fold_affine_weights: bad shape (K %% 8 == 0)");
+    UWIR_CHECK((((uintptr_t)W | (uintptr_t)a | (uintptr_t)s | (uintptr_t)Wb) & 15) == 0, "fold_affine_weights: 16-byte alignment");
+    hipLaunchKernelGGL(fold_affine_weights_kernel, dim3(ceil_div(N, 4), B), dim3(256), 0, (hipStream_t)stream, W, N, K, a, s, bias,
+                       (bf16_t*)Wb, bb);
+    UWIR_LAUNCH_CHECK("fold_affine_weights");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm (U/models/modules/attention.py:76-77,236,254: 32 groups, eps 1e-6, affine) as a folded
 // per-(b,c) affine a*x + s for the consumer GEMM's normalise-on-load.  Statistics: the per-channel
 // shifted partial sums of ln_partial_kernel, merged per group in fp64 (parallel-variance formula).

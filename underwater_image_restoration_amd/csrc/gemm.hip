@@ -637,7 +637,8 @@ __global__ void __launch_bounds__(256, (EPI == EPI_LEAN ? 4 : EPI == EPI_RES ? 3
     const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
     const int M = p.M, K = p.K, N = g.N;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
-    const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt;
+    // per-image weight panels (uwir_fold_affine_weights): a 128-row tile lies inside ONE image (checked on the host)
+    const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt + (g.w_batch_stride ? (size_t)(m0 / (g.OH * g.OW)) * (size_t)g.w_batch_stride : 0);
 
     // staging: wave w owns rows [32w, 32w+32) of both tiles, 4 LDS-DMA pieces of 8 rows each per operand.
     // lane -> (row-in-piece = lane/8, LDS chunk = lane%8) reads GLOBAL chunk (lane%8) ^ (row & 7).
@@ -1639,7 +1640,13 @@ int uwir_gemm_wide_try(const uwir_gemm_args& g, int M, int K, hipStream_t stream
 template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
     GemmP p = p0;
-    if (g_gemm_wide && glds_eligible(p.a, p.K)) {
+    if (p.a.w_batch_stride) {
+        if (!glds_eligible(p.a, p.K) || (p.a.OH * p.a.OW) % 128 != 0 || p.a.w_batch_stride < (long long)p.a.N * p.K ||
+            p.a.w_batch_stride % 8 != 0)
+            return uwir_set_error(UWIR_EUNSUPPORTED, "conv_gemm: w_batch_stride needs a plain bf16 1x1 GEMM (bf16 rows, K %% 64 == 0, "
+                                                     "N > 64), OH * OW %% 128 == 0 and a stride >= N * K, a multiple of 8");
+    }
+    if (g_gemm_wide && !p.a.w_batch_stride && glds_eligible(p.a, p.K)) {
         const int took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
         if (took != 0) return took < 0 ? took : UWIR_OK;
     }

@@ -150,8 +150,9 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
               N: int, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, OH: Optional[int] = None,
               OW: Optional[int] = None, a_scale=None, a_shift=None, bias=None, batch_bias=None, act: int = ACT_NONE,
               res=None, res_scale=None, res_shift=None, store_mode: int = 0, blend_t=None, blend_f=None,
-              blend_out=None, col_scale=None, batch_scale=None, ups: int = 0) -> None:
-    """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h."""
+              blend_out=None, col_scale=None, batch_scale=None, ups: int = 0, w_batched: bool = False) -> None:
+    """out[m,n] = epilogue(sum_k A[m,k] Wt[n,k]); see ``uwir_gemm_args`` in include/uwir.h.  ``w_batched``: Wt is
+    [B, N, K], one weight panel per image (fold_affine_weights)."""
     lib = _lib.load()
     _f32(a_scale, a_shift, bias, batch_bias, res_scale, res_shift, blend_t, blend_f, blend_out, col_scale, batch_scale)
     g = GemmArgs()
@@ -161,7 +162,11 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
     g.OH = OH if OH is not None else ((H << ups) + 2 * pad - KH) // stride + 1
     g.OW = OW if OW is not None else ((W << ups) + 2 * pad - KW) // stride + 1
     g.a_scale, g.a_shift = _p(a_scale), _p(a_shift)
-    if Wt.dim() != 2 or not Wt.is_contiguous() or Wt.shape[0] != N or Wt.shape[1] != KH * KW * C_:
+    if w_batched:
+        if Wt.dim() != 3 or not Wt.is_contiguous() or tuple(Wt.shape) != (B, N, KH * KW * C_):
+            raise ValueError(f"conv_gemm: batched weights must be contiguous [B, N, KH*KW*C], got {tuple(Wt.shape)}")
+        g.w_batch_stride = N * KH * KW * C_
+    elif Wt.dim() != 2 or not Wt.is_contiguous() or Wt.shape[0] != N or Wt.shape[1] != KH * KW * C_:
         raise ValueError(f"conv_gemm: weight must be contiguous [N, KH*KW*C], got {tuple(Wt.shape)}")
     g.Wt, g.w_dtype, g.N = _p(Wt), _dt(Wt), N
     g.bias, g.batch_bias, g.act = _p(bias), _p(batch_bias), act
@@ -194,6 +199,19 @@ def conv_gemm(A: torch.Tensor, Wt: torch.Tensor, out: Optional[torch.Tensor], *,
                 _GEMM_WS[key] = ws
             g.workspace, g.workspace_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.uwir_conv_gemm(C.byref(g), _stream(A)), "conv_gemm")
+
+
+def fold_affine_weights(W: torch.Tensor, a: torch.Tensor, s: torch.Tensor, bias, Wb: torch.Tensor, bb: torch.Tensor) -> None:
+    """Wb[b] = W * a[b] (columns), bb[b] = W s[b] + bias: the per-image LayerNorm2d affine folded into the next 1x1 conv."""
+    _f32(W, a, s, bias, bb)
+    N, K = W.shape
+    Bn = a.shape[0]
+    if (not W.is_contiguous() or tuple(a.shape) != (Bn, K) or tuple(s.shape) != (Bn, K) or not a.is_contiguous()
+            or not s.is_contiguous() or Wb.dtype != torch.bfloat16 or tuple(Wb.shape) != (Bn, N, K) or not Wb.is_contiguous()
+            or tuple(bb.shape) != (Bn, N) or not bb.is_contiguous()):
+        raise ValueError("fold_affine_weights: W [N, K] fp32, a / s [B, K] fp32, Wb [B, N, K] bf16, bb [B, N] fp32, all contiguous")
+    _lib.check(_lib.load().uwir_fold_affine_weights(_p(W), N, K, Bn, _p(a), _p(s), _p(bias), _p(Wb), _p(bb), _stream(W)),
+               "fold_affine_weights")
 
 
 def dwconv_ms(x: torch.Tensor, B: int, H: int, W: int, C_: int, taps, biases, out: torch.Tensor, in_scale=None,

@@ -69,6 +69,7 @@ class NAFNetWFIGate(nn.Module):
         self._streams: dict = {}            # device -> side stream of the SFFB branch
         self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
+        self.fold_norms = True              # bf16: LayerNorm2d affines folded into per-image weight panels (see _wfi_block)
         self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
 
     # ------------------------------------------------------------------ parameters
@@ -153,6 +154,8 @@ class NAFNetWFIGate(nn.Module):
                 b[nm + "_b"] = vec(sd[h + nm + ".norm.bias"])
                 b[nm + "_ss"] = add_cond(sd[h + nm + ".linear.weight"], sd[h + nm + ".linear.bias"])
             b["qkv_w"], b["qkv_b"] = mat(sd[h + "qkv.weight"]), vec(sd[h + "qkv.bias"])
+            if wdt == torch.bfloat16:    # fp32 masters of the two convs that follow a norm: per-image folded panels (forward)
+                b["qkv_w32"], b["ffn0_w32"] = mat(sd[h + "qkv.weight"], f32), mat(sd[h + "ffn.0.weight"], f32)
             b["dw_t"] = tuple(taps(sd[h + f"dw_branches.{i}.weight"]) for i in range(3))
             b["dw_b"] = tuple(vec(sd[h + f"dw_branches.{i}.bias"]) for i in range(3))
             b["merge_w"], b["merge_b"] = mat(sd[h + "dw_merge.weight"]), vec(sd[h + "dw_merge.bias"])
@@ -327,7 +330,17 @@ class NAFNetWFIGate(nn.Module):
         ops.chan_attn_fold(a1, s1, cw, rs, rh)
         qkv_base = buf("qkvb", 3 * Cw, adt)
         bf = adt == torch.bfloat16
-        if bf:  # bf16: one cast pass (norm applied) buys the LDS-DMA GEMM path; fp32: normalise-on-load
+        # bf16: the norm's per-image affine is folded into per-image weight panels W diag(a_b) and bias rows W s_b + bias
+        # (ops.fold_affine_weights, a few microseconds), so the LDS-DMA GEMM reads the un-normalised bf16 rows directly; the
+        # norm-and-cast pass (affine_cast: a full round trip of the activation) is only the fallback for shapes the
+        # batched-weight GEMM does not take.  fp32: normalise-on-load in the register-staged GEMM.
+        fold = bf and self.fold_norms and n % 128 == 0 and Cw % 64 == 0
+        if fold:
+            wb = self._buf(tg + "wb_qkv", B * 3 * Cw, Cw, adt, dev).view(B, 3 * Cw, Cw)
+            bbq = small("bb_qkv", 3 * Cw)
+            ops.fold_affine_weights(bp["qkv_w32"], a1, s1, bp["qkv_b"], wb, bbq)
+            ops.conv_gemm(hf, wb, qkv_base, B=B, H=h, W=w, C_=Cw, N=3 * Cw, batch_bias=bbq, w_batched=True)
+        elif bf:
             xn = buf("xn", Cw, adt)
             ops.affine_cast(hf, B, n, Cw, a1, s1, xn)
             ops.conv_gemm(xn, bp["qkv_w"], qkv_base, B=B, H=h, W=w, C_=Cw, N=3 * Cw, bias=bp["qkv_b"])
@@ -348,7 +361,12 @@ class NAFNetWFIGate(nn.Module):
         o, ln_ = bp["norm2_ss"]
         ops.ln2d_affine(x1, B, n, Cw, _EPS, bp["norm2_g"], bp["norm2_b"], cond_all[:, o:o + ln_], a2, s2, None, None, ws)
         hidden = buf("ffh", 2 * Cw, adt)
-        if bf:
+        if fold:
+            wb = self._buf(tg + "wb_ffn", B * 2 * Cw, Cw, adt, dev).view(B, 2 * Cw, Cw)
+            bbf = small("bb_ffn", 2 * Cw)
+            ops.fold_affine_weights(bp["ffn0_w32"], a2, s2, bp["ffn0_b"], wb, bbf)
+            ops.conv_gemm(x1, wb, hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, batch_bias=bbf, act=ops.ACT_GELU, w_batched=True)
+        elif bf:
             ops.affine_cast(x1, B, n, Cw, a2, s2, xn)
             ops.conv_gemm(xn, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, bias=bp["ffn0_b"], act=ops.ACT_GELU)
         else:
