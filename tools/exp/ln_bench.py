@@ -4,7 +4,8 @@ from underwater_image_restoration_amd import ops
 a, b = torch.randn(4096, 4096, device="cuda"), torch.randn(4096, 4096, device="cuda")
 for _ in range(100): a @ b
 for B, n, C in ((16, 16384, 64), (16, 16384, 192), (16, 4096, 128), (16, 4096, 384), (16, 1024, 256), (16, 1024, 768), (16, 65536, 64)):
-    x = torch.randn(B * n, C, device="cuda")
+    dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
+    x = torch.randn(B * n, C, device="cuda").to(dt)
     g, bt = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     ao, so = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
     ws = torch.empty(max(ops.ln2d_workspace_bytes(B, n, C) // 8, 1), dtype=torch.float64, device="cuda")
@@ -16,4 +17,4 @@ for B, n, C in ((16, 16384, 64), (16, 16384, 192), (16, 4096, 128), (16, 4096, 3
     for _ in range(50): f()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
-    print(f"B{B} n{n} C{C}: {us:.1f} us  {x.numel() * 4 / us / 1e6:.2f} TB/s (statistics + finalize)")
+    print(f"B{B} n{n} C{C}: {us:.1f} us  {x.numel() * x.element_size() / us / 1e6:.2f} TB/s (statistics + finalize)")

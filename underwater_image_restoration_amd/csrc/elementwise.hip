@@ -205,6 +205,71 @@ __global__ void __launch_bounds__(256) ln_partial_kernel(const TX* __restrict__ 
     }
 }
 
+// bf16 rows, C % 8 == 0: the same partial sums from 16-byte loads (8 channels per thread; the 4-channel form above moves
+// 8 bytes per load and ran the bf16 sub-band rows at 2.6 TB/s).  Same shift K, same per-thread row order r0 + ty + k * rl
+// and the same fixed-order fp64 combination, but rl differs from the 4-channel form, so the two round differently in the
+// last bits of the fp32 partials (both are deterministic).
+#define LN_SLAB_O 32  // channel octets per block (256 channels)
+__global__ void __launch_bounds__(256) ln_partial8_kernel(const bf16_t* __restrict__ x, int ldx, int n, int C8,
+                                                          double* __restrict__ part, int nchunks) {
+    const int qs = min(C8 - blockIdx.y * LN_SLAB_O, LN_SLAB_O);
+    const int rl = 256 / qs;
+    const int tx = threadIdx.x % qs, ty = threadIdx.x / qs;
+    const int b = blockIdx.z, chunk = blockIdx.x;
+    const int q = blockIdx.y * LN_SLAB_O + tx;
+    __shared__ float red[2][256][8];
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    const bool active = ty < rl;
+    if (active) {
+        const bf16_t* base = x + (size_t)b * n * ldx + 8 * q;
+        float K[8];
+        {
+            const bf16x8 k8 = *reinterpret_cast<const bf16x8*>(base);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) K[j] = (float)k8[j];
+        }
+        const int r0 = chunk * LN_ROWS_PER_BLOCK, r1 = min(n, r0 + LN_ROWS_PER_BLOCK);
+        auto acc8 = [&](const bf16x8& v) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)v[j] - K[j];
+                s[j] += d;
+                ss[j] += d * d;
+            }
+        };
+        int r = r0 + ty;
+        for (; r + 3 * rl < r1; r += 4 * rl) {
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(base + (size_t)r * ldx);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(base + (size_t)(r + rl) * ldx);
+            const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(base + (size_t)(r + 2 * rl) * ldx);
+            const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(base + (size_t)(r + 3 * rl) * ldx);
+            acc8(v0); acc8(v1); acc8(v2); acc8(v3);
+        }
+        for (; r < r1; r += rl) acc8(*reinterpret_cast<const bf16x8*>(base + (size_t)r * ldx));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[0][ty * qs + tx][j] = s[j];
+            red[1][ty * qs + tx][j] = ss[j];
+        }
+    }
+    __syncthreads();
+    // 8 * qs (channel) outputs: thread t < 8 * qs combines channel (t / 8 -> octet, t % 8) in a fixed order
+    for (int t = threadIdx.x; t < 8 * qs; t += 256) {
+        const int o8 = t >> 3, j = t & 7;
+        double a0 = 0, a1 = 0;
+        for (int l = 0; l < rl; ++l) {
+            a0 += (double)red[0][l * qs + o8][j];
+            a1 += (double)red[1][l * qs + o8][j];
+        }
+        const int C = 8 * C8, c = 8 * (blockIdx.y * LN_SLAB_O + o8) + j;
+        double* o = part + (((size_t)b * nchunks + chunk) * C + c) * 2;
+        o[0] = a0;
+        o[1] = a1;
+    }
+}
+
 template <typename TX>
 __global__ void __launch_bounds__(256) ln_finalize_kernel(const TX* __restrict__ x, int ldx, int n, int C,
                                                           const double* __restrict__ part, int nchunks, float eps,
@@ -280,7 +345,14 @@ extern "C" int uwir_ln2d_affine(const void* x, int x_dtype, int ldx, int B, int 
     hipLaunchKernelGGL(ln_finalize_kernel<TX_>, dim3(ceil_div(B * C * 16, 256)), dim3(256), 0, (hipStream_t)stream,       \
                        (const TX_*)x, ldx, n, C, (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld, \
                        a_out, s_out, mean_out, pooled_out, B);
-    if (x_dtype == UWIR_BF16) { LN2D_LAUNCH(bf16_t) } else { LN2D_LAUNCH(float) }
+    if (x_dtype == UWIR_BF16 && C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+        hipLaunchKernelGGL(ln_partial8_kernel, dim3(nchunks, ceil_div(C / 8, LN_SLAB_O), B), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, ldx, n, C / 8, (double*)workspace, nchunks);
+        UWIR_LAUNCH_CHECK("ln_partial8");
+        hipLaunchKernelGGL(ln_finalize_kernel<bf16_t>, dim3(ceil_div(B * C * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, ldx, n, C, (const double*)workspace, nchunks, eps, gamma, beta, scale_shift, ss_ld,
+                           a_out, s_out, mean_out, pooled_out, B);
+    } else if (x_dtype == UWIR_BF16) { LN2D_LAUNCH(bf16_t) } else { LN2D_LAUNCH(float) }
 #undef LN2D_LAUNCH
     UWIR_LAUNCH_CHECK("ln_finalize");
     return UWIR_OK;
