@@ -47,6 +47,10 @@ void uwir_dwconv_tiles_per_block(int nt);
 /* Measurement switch, no counterpart in the reference: where the packed-stream attention kernel sums its softmax
  * denominators when the V^T tile has no spare row (-1 = per-shape default, 0 = ones-operand MFMA, 1 = packed fp32 adds). */
 void uwir_attn_variant(int lsv);
+/* Measurement switch, no counterpart in the reference: bit 0 clear keeps the student's head conv on bf16 rows on the
+ * per-pixel tile kernel, bit 1 set keeps its stem conv into bf16 rows on the thread-per-pixel kernel; 1 (default) takes the
+ * MFMA kernels for both (hi + lo operand splits: they agree with the exact forms to ~2^-16). */
+void uwir_head_variant(int variant);
 const char* uwir_last_error(void);
 
 /* ---- S/dwt_fft.py:33-39 dwt2 -------------------------------------------------------------

@@ -476,6 +476,62 @@ def test_stem_and_head(ops):
         assert err(pre, ref) < 2e-5 and err(o, ref.clamp(0, 1)) < 2e-5, cin
 
 
+@pytest.mark.parametrize("cin", [64, 32])
+def test_head_mfma_on_bf16_rows(ops, cin):
+    """The student's head on bf16 rows (bf16 mode) runs on the matrix cores with hi + lo splits of the normalised input and
+    of the weights: against fp64 on the same bf16 rows, and against the per-pixel kernel it replaces (uwir_head_variant)."""
+    from underwater_image_restoration_amd import _lib
+    g = torch.Generator().manual_seed(111)
+    b, h, w = 2, 41, 53                                             # ragged in both directions (16-px strips, 32-row blocks)
+    x = torch.rand(b, 3, h, w, generator=g)
+    feat = (torch.randn(b, cin, h, w, generator=g) * 3).bfloat16()
+    wh, bh = torch.randn(3, cin, 3, 3, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1
+    asc, ash = torch.rand(b, cin, generator=g) + 0.5, torch.randn(b, cin, generator=g)
+    fa = feat.double() * asc.double()[:, :, None, None] + ash.double()[:, :, None, None]
+    pre_ref = F.conv2d(fa, wh.double(), bh.double(), padding=1) + x.double()
+    rows = torch.full((b * h * w, cin + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    rows[:, :cin] = to_rows(feat.float()).bfloat16()
+    args = (rows[:, :cin], b, h, w, cin, asc.cuda(), ash.cuda(), wh.permute(0, 2, 3, 1).contiguous().cuda(), bh.cuda(), 3, x.cuda())
+    o = torch.empty(b, 3, h, w, device="cuda")
+    ops.head_conv3x3(*args, o, None)
+    scale = float(pre_ref.abs().max())
+    assert err(o, pre_ref.clamp(0, 1)) < 4e-5 * scale
+    _lib.load().uwir_head_variant(0)
+    try:
+        o2 = torch.empty(b, 3, h, w, device="cuda")
+        ops.head_conv3x3(*args, o2, None)
+    finally:
+        _lib.load().uwir_head_variant(1)
+    assert err(o2, pre_ref.clamp(0, 1)) < 2e-5 * scale and err(o, o2) < 4e-5 * scale
+    pre = torch.empty(b, 3, h, w, device="cuda")                    # a pre-clamp tap keeps the exact kernel
+    ops.head_conv3x3(*args, o2, pre)
+    assert err(pre, pre_ref) < 2e-5 * scale
+
+
+def test_stem_mfma_into_bf16_rows(ops):
+    """The student's stem into bf16 rows (bf16 mode) on the matrix cores, against fp64 and the thread-per-pixel kernel."""
+    from underwater_image_restoration_amd import _lib
+    g = torch.Generator().manual_seed(112)
+    for cin, (b, h, w) in ((3, (2, 37, 50)), (1, (1, 8, 16)), (4, (1, 33, 17))):
+        x = torch.rand(b, cin, h, w, generator=g)
+        ws_, bs_ = torch.randn(64, cin, 3, 3, generator=g) * 0.2, torch.randn(64, generator=g)
+        ref = F.conv2d(x.double(), ws_.double(), bs_.double(), padding=1)
+        wd = ws_.permute(2, 3, 1, 0).contiguous().cuda()
+        out = torch.full((b * h * w, 64 + 8), 3.0, device="cuda", dtype=torch.bfloat16)
+        ops.stem_conv3x3(x.cuda(), wd, bs_.cuda(), out[:, :64])
+        _lib.load().uwir_head_variant(1 | 2)
+        try:
+            old = torch.empty(b * h * w, 64, device="cuda", dtype=torch.bfloat16)
+            ops.stem_conv3x3(x.cuda(), wd, bs_.cuda(), old)
+        finally:
+            _lib.load().uwir_head_variant(1)
+        scale = float(ref.abs().max())
+        assert err(from_rows(out[:, :64], b, h, w), ref) < 5e-3 * scale and float(out[:, 64:].float().min()) == 3.0   # bf16 rows
+        # same fp32 value to ~2^-16 before the one rounding: the two bf16 results differ by at most one bf16 ulp, rarely
+        d = (out[:, :64].float() - old.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * scale and float((d > 0).float().mean()) < 0.02
+
+
 def test_sde_steps(ops):
     g = torch.Generator().manual_seed(12)
     for numel in (3 * 64 * 64 * 2, 1027):

@@ -876,12 +876,122 @@ __global__ void __launch_bounds__(256) stem_pixel_kernel(const float* __restrict
     }
 }
 
+// The student's stem (3x3, Cin <= 4 -> Cout = 64, fp32 NCHW image -> NHWC rows) on the matrix cores.  K = 9 taps x 4
+// channel slots (the 4th, and the 3rd of a 2-channel input, zero) = 36, padded to 64: two k-steps of
+// v_mfma_f32_16x16x32_bf16 per 16 pixels and 16-channel tile; a lane's 8-element piece of a k-step is two taps of ONE pixel
+// column, gathered from the NCHW planes (the image is 4 % of the bytes this kernel moves) and split hi + lo, as are the
+// weights (hi x hi + lo x hi + hi x lo: the fp32 product to ~2^-16, the output rows are the only rounding in bf16 mode).
+// Output as in the 7x7 stem kernel of the UNet: a lane owns 16 consecutive channels of its pixel.  The thread-per-pixel
+// form wrote its 134 MB of bf16 rows at 0.7 TB/s (B = 16, 256 x 256).
+__device__ __forceinline__ int chan_perm16(int rho) {   // gemm.hip's chan_perm: LDS row j * 16 + r holds channel (r >> 2) * 16 + j * 4 + (r & 3)
+    return (rho & 64) | (((rho >> 2) & 3) << 4) | (((rho >> 4) & 3) << 2) | (rho & 3);
+}
+template <typename TO>
+__global__ void __launch_bounds__(256) stem3_mfma_kernel(const float* __restrict__ x, int Cin, int H, int W,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         TO* __restrict__ out, int ldo, const uwir_window* __restrict__ win,
+                                                         int FH, int FW, int NF) {
+    constexpr int NFR = 2 * 4;                                     // fragments: (k-step s, channel tile j)
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[2 * NFR * 64 * 8];   // [hi | lo][fragment][lane][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.z;
+    if (win && !window_ok(win[b], NF, FH, FW, H)) return;          // block-uniform, before the barrier
+    // k = 32 s + 8 fq + e  ->  tap t = 8 s + 2 fq + (e >> 2), channel slot e & 3; taps >= 9 and slots >= Cin are zero
+    for (int i = tid; i < NFR * 64; i += 256) {
+        const int f = i >> 6, l = i & 63, j = f & 3, s2 = f >> 2;
+        const int ch = chan_perm16(j * 16 + (l & 15)), q = l >> 4;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = 8 * s2 + 2 * q + (e >> 2), ci = e & 3;
+            const float v = (t < 9 && ci < Cin) ? w[((size_t)t * Cin + ci) * 64 + ch] : 0.f;   // w is [3, 3, Cin, Cout]
+            const bf16_t h = (bf16_t)v;
+            hi[e] = h;
+            lo[e] = (bf16_t)(v - (float)h);
+        }
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)i * 8]) = hi;
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)(NFR * 64 + i) * 8]) = lo;
+    }
+    __syncthreads();
+    const int x0 = blockIdx.x * 16, ybase = blockIdx.y * 32 + wave * 8;
+    const size_t plane = win ? (size_t)FH * FW : (size_t)H * W;
+    const int rs = win ? FW : W;
+    const float* xb = win ? x + ((size_t)win[b].frame * Cin * FH + win[b].y) * FW + win[b].x : x + (size_t)b * Cin * plane;
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = bias ? bias[fq * 16 + j * 4 + e] : 0.f;
+    const int px = x0 + fr;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        const int y = ybase + r;
+        if (y >= H) break;                                          // wave-uniform
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 8 * s2 + 2 * fq + half;
+                const int iy = y + t / 3 - 1, ix = px + t % 3 - 1;
+                const bool ok = t < 9 && iy >= 0 && iy < H && ix >= 0 && ix < W;   // zero padding at the WINDOW border
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    const float v = (ok && ci < Cin) ? xb[ci * plane + (size_t)iy * rs + ix] : 0.f;
+                    const bf16_t h = (bf16_t)v;
+                    ah[s2][4 * half + ci] = h;
+                    al[s2][4 * half + ci] = (bf16_t)(v - (float)h);
+                }
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){bv[j][0], bv[j][1], bv[j][2], bv[j][3]};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)((s2 * 4 + j) * 64 + lane) * 8]);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)((NFR + s2 * 4 + j) * 64 + lane) * 8]);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[s2], acc[j], 0, 0, 0);
+            }
+        if (px < W) {
+            TO* op = out + (((size_t)b * H + y) * W + px) * ldo + fq * 16;
+            if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                for (int jp = 0; jp < 4; jp += 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)acc[jp][e]; o[4 + e] = (bf16_t)acc[jp + 1][e]; }
+                    *reinterpret_cast<bf16x8*>(op + jp * 4) = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(op + j * 4) = acc[j];
+            }
+        }
+    }
+}
+static int g_stem_mfma = 1;   // tools/ and tests: uwir_head_variant bit 1 set keeps the thread-per-pixel stem
+static bool stem3_ok(int B, int Cin, int H, int Cout, const void* out, int ldo) {
+    return g_stem_mfma && Cin >= 1 && Cin <= 4 && Cout == 64 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0 && B <= 65535 &&
+           ceil_div(H, 32) <= 65535;
+}
+
 extern "C" int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
                                  int Cout, void* outv, int out_dtype, int ldo, uwir_stream_t stream) {
     UWIR_CHECK(x_nchw && w && outv, "stem: null pointer");
     UWIR_CHECK(out_dtype == UWIR_F32 || out_dtype == UWIR_BF16, "stem: bad output dtype");
     float* out = (float*)outv;
     UWIR_CHECK(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout % 4 == 0 && ldo >= Cout && ldo % 4 == 0, "stem: bad shape");
+    if (out_dtype == UWIR_BF16 && stem3_ok(B, Cin, H, Cout, outv, ldo)) {   // (fp32 rows keep the exact fp32 kernel)
+        hipLaunchKernelGGL(stem3_mfma_kernel<bf16_t>, dim3(ceil_div(W, 16), ceil_div(H, 32), B), dim3(256), 0, (hipStream_t)stream,
+                           x_nchw, Cin, H, W, w, bias, (bf16_t*)outv, ldo, (const uwir_window*)nullptr, 0, 0, 0);
+        UWIR_LAUNCH_CHECK("stem(mfma)");
+        return UWIR_OK;
+    }
     if (Cin <= 4 && Cout % 16 == 0 && B <= 65535 && ceil_div(H, 4) <= 65535) {
         if (out_dtype == UWIR_BF16)
             hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0, (hipStream_t)stream,
@@ -908,6 +1018,12 @@ extern "C" int uwir_stem_conv3x3_win(const float* frames, int n_frames, int Cin,
     UWIR_CHECK(n_frames > 0 && nwin > 0 && nwin <= 65535 && T > 0 && T <= FH && T <= FW && ldo >= Cout && ldo % 4 == 0,
                "stem_win: bad shape");
     UWIR_CHECK(Cin >= 1 && Cin <= 4 && Cout % 16 == 0, "stem_win: needs Cin <= 4 and Cout %% 16 == 0");
+    if (out_dtype == UWIR_BF16 && stem3_ok(nwin, Cin, T, Cout, out, ldo)) {
+        hipLaunchKernelGGL(stem3_mfma_kernel<bf16_t>, dim3(ceil_div(T, 16), ceil_div(T, 32), nwin), dim3(256), 0, (hipStream_t)stream,
+                           frames, Cin, T, T, w, bias, (bf16_t*)out, ldo, win, FH, FW, n_frames);
+        UWIR_LAUNCH_CHECK("stem_win(mfma)");
+        return UWIR_OK;
+    }
     if (out_dtype == UWIR_BF16)
         hipLaunchKernelGGL(stem_pixel_kernel<bf16_t>, dim3(ceil_div(T, 64), ceil_div(T, 4), nwin), dim3(256), 0, (hipStream_t)stream,
                            frames, nwin, Cin, T, T, w, bias, Cout, (bf16_t*)out, ldo, win, FH, FW, n_frames);
@@ -1067,6 +1183,144 @@ __global__ void __launch_bounds__(256) head_tile_kernel(const TX* __restrict__ x
     }
 }
 
+// The student's head (final LayerNorm2d affine -> conv3x3 64 -> <= 4 -> + input -> clamp, S/model.py:158-161) on bf16
+// rows on the matrix cores, same scheme as the tail kernel above: output channels as MFMA rows, 16 pixels of an image row
+// as columns, a wave walks 8 rows of a 16-pixel strip with three input rows of fragments live.  The norm's per-(image,
+// channel) affine a x + s is folded into the block's weights (a block serves one image): w' = w a enters LDS as hi + lo
+// bf16 pairs (two MFMAs per fragment: the bf16 rows are exact operands, nothing of the last layer is rounded to bf16), and
+// the shift becomes one constant per (tap, output channel), T[t][co] = sum_c w[co][t][c] s[c], added for the taps that lie
+// inside the image -- the conv pads with zeros AFTER the norm, so border pixels take fewer of them.  Window mode as in
+// head_tile_kernel.  The per-pixel tile kernel read its bf16 rows at 0.75 TB/s.
+template <int NCH>
+__global__ void __launch_bounds__(256) head_mfma_kernel(const bf16_t* __restrict__ x, int ldx, int H, int W,
+                                                        const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                        const float* __restrict__ res, float* __restrict__ out, int do_clamp,
+                                                        const uwir_window* __restrict__ win, int FH, int FW, int NF) {
+    constexpr int NF9 = 9 * NCH, Cin = 32 * NCH;
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[2 * NF9 * 64 * 8];   // [hi | lo][fragment = tap * NCH + chunk][lane][8]
+    __shared__ float s_tap[9][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.z;
+    uwir_window wd = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (win) {                                                      // block-uniform exits come before the barrier
+        wd = win[b];
+        if (!window_ok(wd, NF, FH, FW, H) || !window_core_ok(wd, H)) return;
+        const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 32;
+        if (wd.y + y0 >= wd.cy1 || wd.y + y0 + 32 <= wd.cy0 || wd.x + x0 >= wd.cx1 || wd.x + x0 + 16 <= wd.cx0) return;
+    }
+    for (int i = tid; i < NF9 * 64; i += 256) {
+        const int f = i >> 6, l = i & 63, co = l & 15, kq = l >> 4, tap = f / NCH, c = f % NCH;
+        bf16x8 hi, lo;
+        float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (co < Cout) {
+            const float* wp = w + ((size_t)co * 9 + tap) * Cin + c * 32 + kq * 8;
+            const float4 w0 = load4(wp), w1 = load4(wp + 4);
+            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+            if (a_scale) {
+                const float* ap = a_scale + (size_t)b * Cin + c * 32 + kq * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] *= ap[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wv[j];
+            const bf16_t h = (bf16_t)v;
+            hi[j] = h;
+            lo[j] = (bf16_t)(v - (float)h);
+        }
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)i * 8]) = hi;
+        *reinterpret_cast<bf16x8*>(&s_w[(size_t)(NF9 * 64 + i) * 8]) = lo;
+    }
+    if (tid < 36) {                                                 // T[tap][co]: the shift's share of every tap
+        const int tap = tid >> 2, co = tid & 3;
+        float t = 0.f;
+        if (a_shift && co < Cout) {
+            const float* wp = w + ((size_t)co * 9 + tap) * Cin;
+            const float* sp = a_shift + (size_t)b * Cin;
+            for (int c = 0; c < Cin; ++c) t = fmaf(wp[c], sp[c], t);
+        }
+        s_tap[tap][co] = t;
+    }
+    __syncthreads();
+    const int px = blockIdx.x * 16 + fr, ybase = blockIdx.y * 32 + wave * 8;
+    const bf16_t* xb = x + (size_t)b * H * W * ldx + fq * 8;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (bias && e < Cout) ? bias[e] : 0.f;
+    auto load_row = [&](int iy, bf16x8 (&dst)[3 * NCH]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = px + kx - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const bf16_t* src = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ldx;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c * 32);
+                if (!ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+                }
+                dst[kx * NCH + c] = v;
+            }
+        }
+    };
+    bf16x8 rows[3][3 * NCH];
+    load_row(ybase - 1, rows[0]);
+    load_row(ybase, rows[1]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = ybase + r;
+        if (y < H) {                                                // wave-uniform
+            load_row(y + 1, rows[(r + 2) % 3]);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: hi and lo weights
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < 3 * NCH; ++t) {
+                    const int f = ky * 3 * NCH + t;
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)(f * 64 + lane) * 8]);
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&s_w[(size_t)((NF9 + f) * 64 + lane) * 8]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rows[(r + ky) % 3][t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, rows[(r + ky) % 3][t], acc1, 0, 0, 0);
+                }
+            bool own = fq == 0 && px < W;
+            if (win) own = own && wd.y + y >= wd.cy0 && wd.y + y < wd.cy1 && wd.x + px >= wd.cx0 && wd.x + px < wd.cx1;
+            if (own) {
+                float tb[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = y + t / 3 - 1, ix = px + t % 3 - 1;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tb[e] += s_tap[t][e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < Cout) {
+                        const size_t o = win ? (((size_t)wd.frame * Cout + e) * FH + wd.y + y) * FW + wd.x + px
+                                             : (((size_t)b * Cout + e) * H + y) * W + px;
+                        float v = (acc0[e] + acc1[e]) + tb[e];
+                        if (res) v += res[o];
+                        out[o] = do_clamp ? fminf(fmaxf(v, 0.f), 1.f) : v;
+                    }
+            }
+        }
+    }
+}
+
+static bool head_mfma_ok(const void* x, int ldx, int B, int H, int Cin, const float* w, const float* preclamp) {
+    return (Cin == 32 || Cin == 64) && !preclamp && ldx % 8 == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && B <= 65535 &&
+           ceil_div(H, 32) <= 65535;
+}
+static int g_head_mfma = 1;   // tools/: uwir_head_variant(0) keeps the per-pixel tile kernel
+extern "C" void uwir_head_variant(int v) {
+    g_head_mfma = v & 1;
+    g_stem_mfma = (v & 2) ? 0 : 1;
+}
+
 static bool head_tiled_ok(int B, int Ho, int Wo, int Cin) {
     return Cin % HT_CC == 0 && B <= 65535 && ceil_div(Ho, HT_H) <= 65535;
 }
@@ -1082,6 +1336,17 @@ extern "C" int uwir_head_conv3x3(const void* xv, int x_dtype, int ldx, int B, in
                    ldx % 4 == 0,
                "head: bad shape (Cout<=%d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head: a_scale/a_shift must come together");
+    if (g_head_mfma && x_dtype == UWIR_BF16 && head_mfma_ok(xv, ldx, B, H, Cin, w, preclamp_nchw)) {
+        const dim3 grid(ceil_div(W, 16), ceil_div(H, 32), B);
+        if (Cin == 64)
+            hipLaunchKernelGGL((head_mfma_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W,
+                               a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, 1, (const uwir_window*)nullptr, 0, 0, 0);
+        else
+            hipLaunchKernelGGL((head_mfma_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xv, ldx, H, W,
+                               a_scale, a_shift, w, bias, Cout, residual_nchw, out_nchw, 1, (const uwir_window*)nullptr, 0, 0, 0);
+        UWIR_LAUNCH_CHECK("head(mfma)");
+        return UWIR_OK;
+    }
     if (head_tiled_ok(B, H, W, Cin)) {
         if (x_dtype == UWIR_BF16)
             hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(W, HT_W), ceil_div(H, HT_H), B), dim3(256), 0,
@@ -1114,6 +1379,17 @@ extern "C" int uwir_head_conv3x3_win(const void* x, int x_dtype, int ldx, int nw
                "head_win: bad shape (Cin %% 16 == 0, Cout <= %d)", HEAD_MAX_COUT);
     UWIR_CHECK((a_scale == nullptr) == (a_shift == nullptr), "head_win: a_scale/a_shift must come together");
     UWIR_CHECK(x_dtype == UWIR_F32 || x_dtype == UWIR_BF16, "head_win: bad input dtype");
+    if (g_head_mfma && x_dtype == UWIR_BF16 && head_mfma_ok(x, ldx, nwin, T, Cin, w, nullptr)) {
+        const dim3 grid(ceil_div(T, 16), ceil_div(T, 32), nwin);
+        if (Cin == 64)
+            hipLaunchKernelGGL((head_mfma_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, T, T,
+                               a_scale, a_shift, w, bias, Cout, frames_in, frames_out, 1, win, FH, FW, n_frames);
+        else
+            hipLaunchKernelGGL((head_mfma_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, T, T,
+                               a_scale, a_shift, w, bias, Cout, frames_in, frames_out, 1, win, FH, FW, n_frames);
+        UWIR_LAUNCH_CHECK("head_win(mfma)");
+        return UWIR_OK;
+    }
     if (x_dtype == UWIR_BF16)
         hipLaunchKernelGGL(head_tile_kernel<bf16_t>, dim3(ceil_div(T, HT_W), ceil_div(T, HT_H), nwin), dim3(256), 0,
                            (hipStream_t)stream, (const bf16_t*)x, ldx, T, T, Cin, a_scale, a_shift, w, bias, Cout, frames_in,
