@@ -65,6 +65,52 @@ def test_student_256_bf16_psnr(student_case):
     assert p >= 50.0 and d <= 0.05
 
 
+# ---- configs[4]: 512 x 512, n = 65536 tokens at level 0 (the per-dimension score bound and the online-max fallback of the
+# two-V attention are live here: DESIGN.md).  The golden vectors are ORACLE-generated (tests/golden/cases.py: the reference's
+# un-chunked CFC needs 68.7 GB at this size); the oracle itself is pinned to the reference at 256 x 256 and below.
+@pytest.fixture(scope="module")
+def student_case_512():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.golden.cases import STUDENT_ORACLE_CASES
+    from underwater_image_restoration_amd.synth import student_param_shapes, synth_student_inputs
+    cfg = STUDENT_ORACLE_CASES["prod512"]
+    mk = dict(base_channels=cfg["base_channels"], num_levels=3, blocks_per_level=cfg["blocks_per_level"],
+              cond_dim=cfg["cond_dim"], num_masks=cfg["num_masks"], num_degradation_types=cfg["num_deg"])
+    sd = synth_state_dict(student_param_shapes(**mk), seed=cfg["wseed"])
+    x, z, m = synth_student_inputs(cfg["batch"], cfg["H"], cfg["W"], cfg["cond_dim"], cfg["num_masks"],
+                                   mask_hw=cfg["mask_hw"], seed=cfg["xseed"])
+    gold = np.load(os.path.join(GOLDEN, "student_prod512.npz"))
+    return mk, sd, x, z, m, gold
+
+
+def test_student_512_fp32_elementwise(student_case_512):
+    mk, sd, x, z, m, gold = student_case_512
+    model = _student(mk, sd, "fp32")
+    taps = {}
+    out, alphas, logits = model(x.cuda(), z.cuda(), m.cuda(), taps=taps)
+    torch.cuda.synchronize()
+    pre_ref = gold["pre_clamp_f64"]
+    e_pre = max_abs(taps["pre_clamp"].cpu().numpy(), pre_ref)
+    e_out = max_abs(out.cpu().numpy(), np.clip(pre_ref, 0.0, 1.0))
+    e_log = max_abs(logits.cpu().numpy(), gold["logits_f64"])
+    print(f"\n[student prod512/fp32] vs the fp64 oracle: out {e_out:.3e}  pre-clamp {e_pre:.3e}  logits {e_log:.3e}")
+    assert e_out <= FP32_TOL and e_pre <= FP32_TOL and e_log <= 1e-3
+    from tests.golden.cases import compress
+    assert max_abs(compress(alphas[-1]), gold["alpha_last_f64"]) < 1e-3
+
+
+def test_student_512_bf16_psnr(student_case_512):
+    mk, sd, x, z, m, gold = student_case_512
+    ref = torch.from_numpy(np.clip(gold["pre_clamp_f64"], 0.0, 1.0))
+    model = _student(mk, sd, "bf16")
+    out = model(x.cuda(), z.cuda(), m.cuda())[0].cpu()
+    p, d = psnr(out, ref), psnr_delta_at(out, ref)
+    print(f"\n[student prod512/bf16] PSNR(build, fp64 oracle) = {p:.2f} dB, max abs {float((out.double() - ref).abs().max()):.3e}, "
+          f"PSNR delta at a 30 dB target = {d:.4f} dB")
+    assert p >= 50.0 and d <= 0.05
+
+
 def _unet(cfg, sd, precision):
     from underwater_image_restoration_amd.unet import ConditionalUNet
     m = ConditionalUNet(3, 3, cfg["nf"], cfg["ch_mult"], 512, cfg["degra"], cfg["image"], precision=precision)
