@@ -83,3 +83,22 @@ def test_student_oracle_matches_reference_at_production_size():
     assert max_abs(out.numpy(), gold["out"]) < 2 * TOL
     assert max_abs(taps["pre_clamp"].numpy(), gold["pre_clamp_f64"]) < TOL
     assert max_abs(logits.numpy(), gold["logits_f64"]) < 1e-4
+
+
+def test_prod512_golden_file_is_oracle_generated_and_sane():
+    """tests/golden/student_prod512.npz (512 x 512, configs[4] shapes) is ORACLE-generated in fp64 (the reference's CFC
+    cannot run that size in this container: tests/golden/cases.py); re-running the generator takes ~20 minutes, so here
+    only the file's contract is checked: loads without pickle, the restored image is the clamp of the stored pre-clamp
+    map, and the recorded fp32-vs-fp64 noise of the oracle itself is the figure the GPU test's tolerance argues from."""
+    import os
+    import numpy as np
+    from tests.helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "student_prod512.npz"), allow_pickle=False)
+    assert str(g["generated_by"]) == "oracle/student_ref.py fp64"
+    pre = g["pre_clamp_f64"]
+    assert pre.shape == (1, 3, 512, 512) and pre.dtype == np.float32 and np.isfinite(pre).all()
+    out = np.clip(pre, 0.0, 1.0)
+    assert 0.01 < float(((out == 0) | (out == 1)).mean()) < 0.5       # not clamp-saturated: the comparison means something
+    mx, p9999, mean = (float(v) for v in g["oracle_fp32_vs_fp64_max_p9999_mean"])
+    assert 5e-5 < mx < 2e-4 and p9999 < 1e-4 and mean < 1e-5
+    assert g["logits_f64"].shape == (1, 10)
