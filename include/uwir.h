@@ -39,8 +39,15 @@ int uwir_version(void);
  * the radix-2 FFT line kernel instead of the radix-4 one (same transform, another summation order), bits 3-5 pick the
  * 3x3 conv kernel for bf16 rows (0 = by shape, the default; 1 = the register-staged halo kernel; 2 / 3 / 4 = the LDS-DMA
  * kernel with 8-row tiles and a ring of 4 / 3, or 16-row tiles and a ring of 2; 5 = 16-row tiles, ring of 3; 7 = by shape but never the
- * resident-weight kernel; identical results for every value). */
+ * resident-weight kernel; identical results for every value), bit 6 keeps the large-K 1x1 GEMMs off the 256 x 288 kernel
+ * (N % 288 == 0: the 256 x 192 one where N % 192 == 0, else 128 x 128; same sums in the same order). */
 void uwir_conv_variant(int variant);
+/* Measurement hook with no counterpart in the reference: the 256 x 288 large-K bf16 GEMM (out[M, N] = A[M, K] Wt[N, K]^T + bias,
+ * dense rows; N % 288 == 0, K % 64 == 0, K >= 1024, M >= 4096) or one of its timing-only ablations, which leave `out`
+ * undefined: 0 = the kernel as uwir_conv_gemm launches it, 1 = every wave issues its LDS-DMA right after the stage barrier,
+ * 2 = every wave between the two k-halves, 3 = no MFMAs, 4 = no LDS-DMA inside the K loop, 5 = the LDS-DMA fill alone. */
+int uwir_gemm_wide_probe(const void* A, const void* Wt, void* out, const float* bias, int M, int N, int K, int variant,
+                         uwir_stream_t stream);
 /* Test / measurement switch, no counterpart in the reference: tiles walked by one block of the pipelined depthwise
  * kernel (0 = chosen from the grid size, the default).  Results are identical for every value. */
 void uwir_dwconv_tiles_per_block(int nt);

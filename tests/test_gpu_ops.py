@@ -985,29 +985,35 @@ def test_affine_cast(ops):
         assert err(out[:, :c].reshape(b, n, c), ref) < tol and float(out[:, c:].float().min()) == 4.0
 
 
-@pytest.mark.parametrize("shape", [(4096 + 77, 192, 1024), (8192, 576, 1728), (4500, 384, 2048)])
+@pytest.mark.parametrize("shape", [(4096 + 77, 192, 1024), (8192, 576, 1728), (4500, 384, 2048), (4096 + 77, 288, 1088),
+                                   (4608, 864, 1024)])
 @pytest.mark.parametrize("epi", ["plain", "bias_scale", "gelu"])
 def test_conv_gemm_wide_tiles(ops, shape, epi):
-    """Large-K bf16 1x1 GEMMs with N % 192 == 0 take the 256 x 192 ring kernel (csrc/gemm_wide.hip): ragged M, every
-    epilogue it accepts, against an fp64 reference and against the 128 x 128 kernel (same sums in another order)."""
+    """Large-K bf16 1x1 GEMMs take the 256 x 288 kernel when N % 288 == 0 (csrc/gemm_wide288.hip) and the 256 x 192 ring
+    kernel when N % 192 == 0 (csrc/gemm_wide.hip): ragged M, an odd number of K stages, strided rows, every epilogue they
+    accept, against an fp64 reference, against the 128 x 128 kernel (same sums in another order) and -- where both wide
+    kernels apply -- against each other (the same sums in the same order: bit-equal)."""
     from underwater_image_restoration_amd import _lib
     lib = _lib.load()
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N)
-    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    Abuf = torch.randn(M, K + 8, generator=g).cuda().bfloat16()
+    A = Abuf[:, :K]                                             # lda = K + 8
     W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
     bias = torch.randn(N, generator=g).cuda() if epi != "plain" else None
     cs = (torch.rand(N, generator=g) + 0.5).cuda() if epi == "bias_scale" else None
     act = ops.ACT_GELU if epi == "gelu" else ops.ACT_NONE
     outs = []
-    for variant in (2, 0):   # 2: keep the 128 x 128 kernel
+    for variant in (2, 64, 0):   # 2: keep the 128 x 128 kernel; 64: not the 256 x 288 one
         lib.uwir_conv_variant(variant)
         try:
-            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            obuf = torch.full((M, N + 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+            out = obuf[:, 8:8 + N]                              # ldo = N + 16, 16-byte aligned
             ops.conv_gemm(A, W, out, B=1, H=1, W=M, C_=K, N=N, bias=bias, col_scale=cs, act=act)
             torch.cuda.synchronize()
         finally:
             lib.uwir_conv_variant(0)
+        assert bool(torch.isnan(obuf[:, :8]).all()) and bool(torch.isnan(obuf[:, 8 + N:]).all())   # nothing outside the view
         outs.append(out.float())
     ref = A.double() @ W.double().t()
     if bias is not None:
@@ -1019,7 +1025,34 @@ def test_conv_gemm_wide_tiles(ops, shape, epi):
     for o in outs:
         assert bool(torch.isfinite(o).all())
         assert rel(o, ref.float()) < 4e-3          # bf16 output rounding
-    assert float((outs[0] - outs[1]).abs().max()) <= 2 ** -6 * float(ref.abs().max())   # at most one bf16 ulp apart
+    assert float((outs[0] - outs[2]).abs().max()) <= 2 ** -6 * float(ref.abs().max())   # at most one bf16 ulp apart
+    if N % 288 == 0 and N % 192 == 0:
+        assert torch.equal(outs[1], outs[2])
+
+
+def test_gemm_wide_probe_matches_conv_gemm_and_rejects_other_shapes(ops):
+    """uwir_gemm_wide_probe(variant 0) is the kernel conv_gemm launches for the merge shapes; shapes outside the 256 x 288
+    kernel's range and unknown variants are errors."""
+    from underwater_image_restoration_amd import _lib
+    lib = _lib.load()
+    M, N, K = 4096, 576, 1728
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    o1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    o2 = torch.empty_like(o1)
+    ops.conv_gemm(A, W, o1, B=1, H=1, W=M, C_=K, N=N, bias=bias)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.uwir_gemm_wide_probe(A.data_ptr(), W.data_ptr(), o2.data_ptr(), bias.data_ptr(), M, N, K, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    for v in (1, 2, 3, 4, 5):                                   # the ablations run to completion (their output is undefined)
+        assert lib.uwir_gemm_wide_probe(A.data_ptr(), W.data_ptr(), o2.data_ptr(), bias.data_ptr(), M, N, K, v, st) == 0
+    torch.cuda.synchronize()
+    assert lib.uwir_gemm_wide_probe(A.data_ptr(), W.data_ptr(), o2.data_ptr(), bias.data_ptr(), M, N, K, 6, st) != 0
+    assert lib.uwir_gemm_wide_probe(A.data_ptr(), W.data_ptr(), o2.data_ptr(), None, M, 192, K, 0, st) != 0
+    assert b"288" in lib.uwir_last_error()
 
 
 def test_operand_on_another_device_is_an_error(ops):

@@ -1540,6 +1540,7 @@ static bool halo_eligible(const uwir_gemm_args& g) {
 }
 
 static int g_gemm_wide = 1;   // tools/: uwir_conv_variant(2) keeps the large-K GEMMs on the 128 x 128 kernel
+static int g_gemm_288 = 1;    // tools/: uwir_conv_variant(64) keeps them off the 256 x 288 kernel (256 x 192 where N % 192 == 0)
 static int g_halo_th16 = 0;   // tools/: uwir_conv_variant(1) takes 16-row tiles at N <= 64 (A/B timing: 85 vs 88 us at 256^2
                               // C 64 -> 64, equal elsewhere -- three resident 8-row blocks hide more than the bigger tile saves)
 void uwir_fft_set_radix4(int on);   // fft.hip
@@ -1547,6 +1548,7 @@ extern "C" void uwir_conv_variant(int v) {
     g_halo_th16 = v & 1;
     g_conv_dma = ((v >> 3) & 7) == 0 ? 1 : ((v >> 3) & 7) == 1 ? 0 : ((v >> 3) & 7);
     g_gemm_wide = (v & 2) ? 0 : 1;
+    g_gemm_288 = (v & 64) ? 0 : 1;
     uwir_fft_set_radix4((v & 4) ? 0 : 1);
 }
 
@@ -1635,7 +1637,8 @@ static int splitk_factor(int M, int N, int K, const void* ws, size_t ws_bytes) {
     return s;
 }
 
-int uwir_gemm_wide_try(const uwir_gemm_args& g, int M, int K, hipStream_t stream);   // gemm_wide.hip
+int uwir_gemm_wide_try(const uwir_gemm_args& g, int M, int K, hipStream_t stream);      // gemm_wide.hip
+int uwir_gemm_wide288_try(const uwir_gemm_args& g, int M, int K, hipStream_t stream);   // gemm_wide288.hip
 
 template <typename TC, typename TA>
 static int launch_gemm(const GemmP& p0, hipStream_t stream) {
@@ -1647,7 +1650,8 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
                                                      "N > 64), OH * OW %% 128 == 0 and a stride >= N * K, a multiple of 8");
     }
     if (g_gemm_wide && !p.a.w_batch_stride && glds_eligible(p.a, p.K)) {
-        const int took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
+        int took = g_gemm_288 ? uwir_gemm_wide288_try(p.a, p.M, p.K, stream) : 0;
+        if (took == 0) took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
         if (took != 0) return took < 0 ? took : UWIR_OK;
     }
     int bn = p.a.N <= 64 ? 64 : 128;
