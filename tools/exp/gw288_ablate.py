@@ -32,7 +32,8 @@ for M, N, K in ((262144, 576, 1728), (65536, 1152, 3456), (16384, 2304, 6912)):
         def f():
             assert lib.uwir_gemm_wide_probe(A.data_ptr(), W.data_ptr(), o.data_ptr(), bias.data_ptr(), M, N, K, v, st) == 0
         return f
-    arms = [("conv_gemm 256x192", conv(64)), ("conv_gemm 256x288", conv(0))] + [(f"probe {v}", probe(v)) for v in range(6)]
+    pv = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(6))
+    arms = [("conv_gemm 256x192", conv(64)), ("conv_gemm 256x288", conv(0))] + [(f"probe {v}", probe(v)) for v in pv]
     res = {k: [] for k, _ in arms}
     for _ in range(3):
         for k, f in arms: res[k].append(timeit(f))

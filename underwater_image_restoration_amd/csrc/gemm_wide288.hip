@@ -29,7 +29,11 @@
 // the MFMAs by sched_barrier 3 % slower than the compiler's own interleave.
 // Tried on the 192-wide tile and not kept: fragments double-buffered in registers over the k-halves with the fill issued
 // two stages ahead (same time: the fill is bandwidth-bound, not latency-bound), LDS-DMA instructions spread among the
-// MFMAs (3 % slower).
+// MFMAs (3 % slower).  Tried on this tile and not kept: a second barrier after the last fragment reads of a stage, so that
+// its buffer is restaged for stage t + 2 while the k-half-1 MFMAs still run (two stages in flight): 0.484 -> 0.505-0.525,
+// 0.425 -> 0.457-0.472, 0.398 -> 0.415-0.445 ms -- the barrier costs more than the earlier fill start gains.
+// What is left (uwir_gemm_wide_probe, M262144 N576 K1728): fill alone 0.342 ms, MFMAs + fragment reads alone 0.350, fill +
+// reads + barriers without MFMAs 0.404, whole kernel 0.459 = 1.31 x the larger floor.
 #include "common.h"
 
 #define G3_BM 256
