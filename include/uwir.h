@@ -73,6 +73,21 @@ int uwir_dwt2(const void* x, int x_dtype, int ldx, int B, int H, int W, int C, v
 int uwir_idwt2(const float* ll, int ld_ll, const void* hf, int hf_dtype, int ld_hf, int B, int h, int w, int C, void* out,
                int out_dtype, int ldo, uwir_stream_t stream);
 
+/* ---- S/wfi_gate.py:29-45 WFIGate + S/dwt_fft.py:42-58 idwt2 in one pass (bf16 mode) ----------------------------
+ * gate_in [M = B*h*w, ldg] fp32 rows = [t_out (C) | f_out (C) | masks resized to (h, w) (Kg - 2C columns, zero-padded)],
+ * w1 [64, Kg] bf16 = net.0.weight without its cond columns, bias1 [B, 64] fp32 = net.0.bias + the cond columns applied to
+ * cond_proj(z_d) (per image), w2 [C, 64] bf16 = net.2.weight, b2 [C] fp32:
+ *   alpha = sigmoid(w2 relu(w1 gate_in + bias1) + b2)      -> alpha [M, C] fp32 (the model's alpha map, NHWC)
+ *   merged = alpha t_out + (1 - alpha) f_out               -> merged [M, C] fp32 if not NULL (diagnostic taps)
+ *   out = idwt2(merged, hf)                                -> out [B, 2h, 2w, C] bf16 (pixel stride ldo)
+ * with hf [M, ld_hf] bf16 = [lh | hl | hh].  The same values as uwir_conv_gemm (relu) -> uwir_conv_gemm (sigmoid, blend)
+ * -> uwir_idwt2 up to the summation order inside the bf16 MFMAs; built for C in {64, 128, 256} and Kg = 2C or 2C + 16
+ * (uwir_gate_idwt_supported), other shapes take the three calls. */
+int uwir_gate_idwt_supported(int C, int Kg);
+int uwir_gate_idwt(const float* gate_in, int ldg, int Kg, const void* w1, const void* w2, const float* bias1, const float* b2,
+                   const void* hf, int ld_hf, int B, int h, int w, int C, void* out, int ldo, float* alpha, float* merged,
+                   uwir_stream_t stream);
+
 /* ---- S/utils.py:10-36 LayerNorm2d / AdaLayerNorm2d ------------------------------------------
  * Per-(b,c) statistics over the n = H*W rows of x [B,n,C]; emits the folded affine
  *   LN(x)*(1+scale)+shift == a[b,c]*x + s[b,c]

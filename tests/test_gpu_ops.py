@@ -1030,6 +1030,65 @@ def test_conv_gemm_wide_tiles(ops, shape, epi):
         assert torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("case", [(64, 16, 2, 16, 24), (128, 0, 3, 6, 10), (256, 16, 1, 8, 8)])
+def test_gate_idwt_fused_against_the_three_launches(ops, case):
+    """WFIGate + idwt2 in one launch (csrc/gate.hip) against conv_gemm (relu) -> conv_gemm (sigmoid, blend) -> idwt2 on the
+    same operands, and against fp64 on the bf16-rounded operands: ragged row counts (M % 16 != 0, tiles that straddle two
+    images), with and without mask columns, strided hf / out rows."""
+    C, Mp, B, h, w = case
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(C + Mp)
+    M, Kg = B * h * w, 2 * C + Mp
+    gate_in = torch.randn(M, Kg, generator=g)
+    if Mp:
+        gate_in[:, 2 * C + 10:] = 0.0                              # the zero padding behind the 10 mask columns
+    w1 = (torch.randn(64, Kg, generator=g) / Kg ** 0.5).to(bf)
+    w2 = (torch.randn(C, 64, generator=g) / 8).to(bf)
+    bias1, b2 = torch.randn(B, 64, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    hfb = torch.randn(M, 3 * C + 8, generator=g).to(bf)
+    gi, w1c, w2c, bb, b2c, hfc = gate_in.cuda(), w1.cuda(), w2.cuda(), bias1.cuda(), b2.cuda(), hfb.cuda()
+    hf = hfc[:, :3 * C]
+    # the three launches
+    ghid = torch.empty(M, 64, device="cuda", dtype=bf)
+    ops.conv_gemm(gi, w1c, ghid, B=B, H=h, W=w, C_=Kg, N=64, batch_bias=bb, act=ops.ACT_RELU)
+    alpha0, merged0 = torch.empty(B, h, w, C, device="cuda"), torch.empty(M, C, device="cuda")
+    ops.conv_gemm(ghid, w2c, alpha0.view(M, C), B=B, H=h, W=w, C_=64, N=C, bias=b2c, act=ops.ACT_SIGMOID,
+                  blend_t=gi[:, :C], blend_f=gi[:, C:2 * C], blend_out=merged0)
+    out0 = torch.full((4 * M, C + 8), 7.0, device="cuda", dtype=bf)
+    ops.idwt2(merged0, hf, B, h, w, C, out0[:, :C])
+    # one launch
+    alpha1, merged1 = torch.empty(B, h, w, C, device="cuda"), torch.empty(M, C, device="cuda")
+    out1 = torch.full((4 * M, C + 8), 7.0, device="cuda", dtype=bf)
+    ops.gate_idwt(gi, w1c, w2c, bb, b2c, hf, B, h, w, C, out1[:, :C], alpha1, merged1)
+    torch.cuda.synchronize()
+    assert float(out1[:, C:].float().min()) == 7.0 and float(out1[:, C:].float().max()) == 7.0     # nothing outside the view
+    # fp64 on the same bf16-rounded operands (the hidden rows rounded to bf16 as both forms do)
+    hid = torch.relu(gate_in.to(bf).double() @ w1.double().t() + bias1.double().repeat_interleave(h * w, 0)).to(bf).double()
+    a_ref = torch.sigmoid(hid @ w2.double().t() + b2.double())
+    m_ref = a_ref * gate_in[:, :C].double() + (1 - a_ref) * gate_in[:, C:2 * C].double()
+    assert err(alpha1.view(M, C), a_ref) < 3e-3 and err(merged1, m_ref) < 1e-2       # bf16 rounding flips of the hidden rows
+    assert err(alpha1, alpha0.double()) < 3e-3 and err(merged1, merged0.double()) < 1e-2
+    # inverse transform of ITS OWN merged rows: exact up to the output's bf16 rounding
+    k = float(torch.tensor(0.70710678118654752440, dtype=torch.float32) ** 2)
+    mm = merged1.double().view(B, h, w, C)
+    hh_ = hf.double().view(B, h, w, 3, C)
+    lh, hl, hhh = hh_[..., 0, :], hh_[..., 1, :], hh_[..., 2, :]
+    ref = torch.empty(B, 2 * h, 2 * w, C, dtype=torch.float64, device="cuda")
+    ref[:, 0::2, 0::2] = k * (mm + lh + hl + hhh)
+    ref[:, 0::2, 1::2] = k * (mm - lh + hl - hhh)
+    ref[:, 1::2, 0::2] = k * (mm + lh - hl - hhh)
+    ref[:, 1::2, 1::2] = k * (mm - lh - hl + hhh)
+    got = out1[:, :C].double().view(B, 2 * h, 2 * w, C)
+    assert float(((got - ref).abs() / (ref.abs() + 1.0)).max()) < 2 ** -8
+    assert err(out1[:, :C], out0[:, :C].double()) < 5e-2
+    # without the diagnostic output
+    alpha2 = torch.empty_like(alpha1)
+    out2 = torch.full_like(out1, 7.0)
+    ops.gate_idwt(gi, w1c, w2c, bb, b2c, hf, B, h, w, C, out2[:, :C], alpha2, None)
+    assert torch.equal(out2, out1) and torch.equal(alpha2, alpha1)
+    assert not ops.gate_idwt_supported(48, 96 + 16) and ops.gate_idwt_supported(64, 128)
+
+
 def test_gemm_wide_probe_matches_conv_gemm_and_rejects_other_shapes(ops):
     """uwir_gemm_wide_probe(variant 0) is the kernel conv_gemm launches for the merge shapes; shapes outside the 256 x 288
     kernel's range and unknown variants are errors."""
@@ -1083,6 +1142,37 @@ def test_model_on_non_current_device(ops):
         assert torch.cuda.current_device() == 0
         outs.append(model(x.to(dev), z.to(dev), None)[0].cpu())   # cuda:1 is NOT the current device here
     assert torch.equal(outs[0], outs[1])
+
+
+def test_unet_and_sampler_on_non_current_device(ops):
+    """ConditionalUNet.forward lost its device decorators once; a UNet (and an IRSDE loop around it) on a
+    GPU that is not the current one must run there and give the same result as on the current one."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from underwater_image_restoration_amd.sde import IRSDE
+    from underwater_image_restoration_amd.synth import synth_state_dict, unet_param_shapes
+    from underwater_image_restoration_amd.unet import ConditionalUNet
+    mk = dict(in_nc=3, out_nc=3, nf=32, ch_mult=[1, 2], context_dim=64, use_degra_context=True, use_image_context=True)
+    sd = synth_state_dict(unet_param_shapes(**mk), seed=5)
+    g = torch.Generator().manual_seed(6)
+    mu = torch.rand(1, 3, 32, 32, generator=g)
+    x0 = mu + torch.randn(mu.shape, generator=g) * 0.1
+    tc, ic = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g)
+    tape = torch.randn(3, 1, 3, 32, 32, generator=g)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        net = ConditionalUNet(mk["in_nc"], mk["out_nc"], mk["nf"], mk["ch_mult"], mk["context_dim"], True, True, precision="fp32")
+        net.load_state_dict(sd)
+        net = net.to(dev).eval()
+        assert torch.cuda.current_device() == 0
+        eps = net(x0.to(dev), mu.to(dev), 3, text_context=tc.to(dev), image_context=ic.to(dev))
+        assert eps.device == torch.device(dev) and not eps.requires_grad
+        sde = IRSDE(max_sigma=50, T=100, schedule="cosine", eps=0.005, device=dev)
+        sde.set_mu(mu.to(dev))
+        sde.set_model(net)
+        out = sde.reverse_posterior(x0.to(dev), T=3, noise_tape=tape.to(dev), text_context=tc.to(dev), image_context=ic.to(dev))
+        outs.append((eps.cpu(), out.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_bf16_activation_stream_variants(ops):

@@ -110,6 +110,33 @@ def idwt2(ll: torch.Tensor, hf: torch.Tensor, B: int, h: int, w: int, C: int, ou
                "idwt2")
 
 
+def gate_idwt_supported(C: int, Kg: int) -> bool:
+    return bool(_lib.load().uwir_gate_idwt_supported(C, Kg))
+
+
+def gate_idwt(gate_in: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, bias1: torch.Tensor, b2: torch.Tensor,
+              hf: torch.Tensor, B: int, h: int, w: int, C: int, out: torch.Tensor, alpha: torch.Tensor,
+              merged: Optional[torch.Tensor] = None) -> None:
+    """WFIGate (wfi_gate.py:29-45) + idwt2 in one launch: see include/uwir.h.  bf16 weights / hf / out, fp32 gate rows."""
+    _f32(gate_in, bias1, b2, alpha, merged)
+    bf = torch.bfloat16
+    if w1.dtype != bf or w2.dtype != bf or hf.dtype != bf or out.dtype != bf:
+        raise ValueError("gate_idwt: w1, w2, hf and out must be bf16")
+    Kg = gate_in.shape[1]
+    if tuple(w1.shape) != (64, Kg) or tuple(w2.shape) != (C, 64) or not w1.is_contiguous() or not w2.is_contiguous():
+        raise ValueError("gate_idwt: w1 must be [64, Kg] and w2 [C, 64], contiguous")
+    M = B * h * w
+    if gate_in.shape[0] != M or hf.shape[0] != M or hf.shape[1] < 3 * C or out.shape[0] != 4 * M or out.shape[1] < C:
+        raise ValueError("gate_idwt: row counts do not match B * h * w")
+    if alpha.numel() != M * C or not alpha.is_contiguous() or tuple(bias1.shape) != (B, 64) or not bias1.is_contiguous():
+        raise ValueError("gate_idwt: alpha must be a contiguous [B, h, w, C] and bias1 a contiguous [B, 64]")
+    if merged is not None and (tuple(merged.shape) != (M, C) or not merged.is_contiguous()):
+        raise ValueError("gate_idwt: merged must be a contiguous [M, C]")
+    lib = _lib.load()
+    _lib.check(lib.uwir_gate_idwt(_p(gate_in), _ld(gate_in), Kg, _p(w1), _p(w2), _p(bias1), _p(b2), _p(hf), _ld(hf), B, h, w, C,
+                                  _p(out), _ld(out), _p(alpha), _p(merged), _stream(gate_in)), "gate_idwt")
+
+
 def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
     return int(_lib.load().uwir_ln2d_workspace_bytes(B, n, C_))
 

@@ -70,6 +70,7 @@ class NAFNetWFIGate(nn.Module):
         self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
         self.fold_norms = True              # bf16: LayerNorm2d affines folded into per-image weight panels (see _wfi_block)
+        self.fuse_gate = True               # bf16: WFIGate + idwt2 in one launch (ops.gate_idwt); False keeps the three launches
         self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
 
     # ------------------------------------------------------------------ parameters
@@ -392,14 +393,21 @@ class NAFNetWFIGate(nn.Module):
         o, ln_ = bp["cp"]
         bb = small("gbb", 64)
         ops.linear(cond_all[:, o:o + ln_], bp["gc_w"], bp["g1_b"], bb)
-        ghid = buf("ghid", 64, adt)
         Kg = gate_in.shape[1]
-        ops.conv_gemm(gate_in, bp["g1_w"], ghid, B=B, H=h, W=w, C_=Kg, N=64, batch_bias=bb, act=ops.ACT_RELU)
         alpha = torch.empty(B, h, w, Cc, dtype=f32, device=dev)
-        merged = buf("merged", Cc)
-        ops.conv_gemm(ghid, bp["g2_w"], alpha.view(Mr, Cc), B=B, H=h, W=w, C_=64, N=Cc, bias=bp["g2_b"],
-                      act=ops.ACT_SIGMOID, blend_t=gate_in[:, :Cc], blend_f=gate_in[:, Cc:2 * Cc], blend_out=merged)
-        ops.idwt2(merged, hf_out, B, h, w, Cc, out)
+        # bf16: gate MLP, blend and the inverse transform in one launch (csrc/gate.hip): the hidden rows, the merged rows
+        # and the second read of t / f never reach HBM (3.0 -> 1.7 KB per sub-band pixel at C = 64)
+        fused_gate = bf and self.fuse_gate and out.dtype == torch.bfloat16 and ops.gate_idwt_supported(Cc, Kg)
+        if fused_gate:
+            merged = buf("merged", Cc) if taps is not None else None
+            ops.gate_idwt(gate_in, bp["g1_w"], bp["g2_w"], bb, bp["g2_b"], hf_out, B, h, w, Cc, out, alpha, merged)
+        else:
+            ghid = buf("ghid", 64, adt)
+            ops.conv_gemm(gate_in, bp["g1_w"], ghid, B=B, H=h, W=w, C_=Kg, N=64, batch_bias=bb, act=ops.ACT_RELU)
+            merged = buf("merged", Cc)
+            ops.conv_gemm(ghid, bp["g2_w"], alpha.view(Mr, Cc), B=B, H=h, W=w, C_=64, N=Cc, bias=bp["g2_b"],
+                          act=ops.ACT_SIGMOID, blend_t=gate_in[:, :Cc], blend_f=gate_in[:, Cc:2 * Cc], blend_out=merged)
+            ops.idwt2(merged, hf_out, B, h, w, Cc, out)
         if taps is not None:
             nchw = lambda t, c: t[:, :c].reshape(B, h, w, c).permute(0, 3, 1, 2).float().clone()  # noqa: E731
             taps.update(hf=nchw(hf_out, Cw), lf=nchw(lf, Cc), t_out=nchw(gate_in, Cc),
