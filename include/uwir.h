@@ -88,6 +88,19 @@ int uwir_gate_idwt(const float* gate_in, int ldg, int Kg, const void* w1, const 
                    const void* hf, int ld_hf, int B, int h, int w, int C, void* out, int ldo, float* alpha, float* merged,
                    uwir_stream_t stream);
 
+/* ---- S/wtb.py:117-124 the WTB's feed-forward block in one pass (bf16 mode) -----------------------------------------
+ *   out = W2 gelu(W0_b x + bias0_b) + b2 + x                 (exact erf GELU, as nn.GELU())
+ * x [B*n, ldx] bf16 rows with C channels (the block's residual stream), w0_batched [B][2C][C] bf16 and bias0_batched [B][2C]
+ * fp32 = ffn.0 with the norm2 affine of image b folded in (uwir_fold_affine_weights; w0_batch_stride elements between
+ * images), w2_permuted [C][2C] bf16 = ffn.2.weight with the columns of every 32-block in the order
+ * 4q + e, 16 + 4q + e (q = 0..3, e = 0..3) -- position 8q + e' holds column 4q + e' (e' < 4) or 16 + 4q + e' - 4 --, b2 [C],
+ * out [B*n, ldo] bf16 (may alias nothing else).  The [B*n, 2C] hidden tensor of the two-launch form (uwir_conv_gemm with
+ * GELU, uwir_conv_gemm with the residual) never reaches HBM.  Built for C = 192 (n % 256 == 0) and C = 384 (n % 128 == 0):
+ * uwir_ffn_fused_supported; other shapes take the two launches. */
+int uwir_ffn_fused_supported(int C, int n);
+int uwir_ffn_fused(const void* x, int ldx, const void* w0_batched, long long w0_batch_stride, const float* bias0_batched,
+                   const void* w2_permuted, const float* b2, int B, int n, int C, void* out, int ldo, uwir_stream_t stream);
+
 /* ---- S/utils.py:10-36 LayerNorm2d / AdaLayerNorm2d ------------------------------------------
  * Per-(b,c) statistics over the n = H*W rows of x [B,n,C]; emits the folded affine
  *   LN(x)*(1+scale)+shift == a[b,c]*x + s[b,c]

@@ -1089,6 +1089,45 @@ def test_gate_idwt_fused_against_the_three_launches(ops, case):
     assert not ops.gate_idwt_supported(48, 96 + 16) and ops.gate_idwt_supported(64, 128)
 
 
+@pytest.mark.parametrize("case", [(192, 3, 512), (384, 2, 384)])
+def test_ffn_fused_against_the_two_launches(ops, case):
+    """ffn.0 -> GELU -> ffn.2 + residual in one launch (csrc/ffn.hip) against the two uwir_conv_gemm launches it replaces
+    (per-image folded weights, batched bias) and against fp64 on the same bf16 operands; strided rows, several passes per
+    block, images whose weights differ."""
+    C, B, n = case
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(C)
+    M = B * n
+    xb = torch.randn(M, C + 8, generator=g).to(bf).cuda()
+    x = xb[:, :C]
+    w0b = (torch.randn(B, 2 * C, C, generator=g) / C ** 0.5).to(bf).cuda()
+    bias0 = (torch.randn(B, 2 * C, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, 2 * C, generator=g) / (2 * C) ** 0.5).to(bf).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
+    assert ops.ffn_fused_supported(C, n) and not ops.ffn_fused_supported(C, n + 16) and not ops.ffn_fused_supported(768, 1024)
+    # two launches
+    hidden = torch.empty(M, 2 * C, device="cuda", dtype=bf)
+    ops.conv_gemm(x, w0b, hidden, B=B, H=1, W=n, C_=C, N=2 * C, batch_bias=bias0, act=ops.ACT_GELU, w_batched=True)
+    out0 = torch.empty(M, C, device="cuda", dtype=bf)
+    ops.conv_gemm(hidden, w2, out0, B=B, H=1, W=n, C_=2 * C, N=C, bias=b2, res=x)
+    # one launch
+    w2p = ops.ffn_permute_w2(w2)
+    obuf = torch.full((M, C + 16), 5.0, device="cuda", dtype=bf)
+    out1 = obuf[:, 8:8 + C]
+    ops.ffn_fused(x, w0b, bias0, w2p, b2, B, n, C, out1)
+    torch.cuda.synchronize()
+    assert float(obuf[:, :8].float().min()) == 5.0 and float(obuf[:, 8 + C:].float().max()) == 5.0
+    # fp64 with the hidden rows rounded to bf16 as both forms do
+    xd = x.double().view(B, n, C)
+    hid = torch.einsum("bnc,bhc->bnh", xd, w0b.double()) + bias0.double()[:, None]
+    hid = torch.nn.functional.gelu(hid).to(bf).double()
+    ref = (hid.view(M, 2 * C) @ w2.double().t() + b2.double() + x.double())
+    assert rel(out1, ref) < 6e-3 and rel(out0, ref) < 6e-3          # bf16 output rounding + rounding flips of hidden rows
+    d = (out1.float() - out0.float()).abs()
+    assert float(d.max()) <= 2 ** -6 * float(ref.abs().max())        # at most about one bf16 ulp apart
+    assert float((d > 0).float().mean()) < 0.05
+
+
 def test_gemm_wide_probe_matches_conv_gemm_and_rejects_other_shapes(ops):
     """uwir_gemm_wide_probe(variant 0) is the kernel conv_gemm launches for the merge shapes; shapes outside the 256 x 288
     kernel's range and unknown variants are errors."""

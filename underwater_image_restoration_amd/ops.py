@@ -137,6 +137,37 @@ def gate_idwt(gate_in: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, bias1: 
                                   _p(out), _ld(out), _p(alpha), _p(merged), _stream(gate_in)), "gate_idwt")
 
 
+def ffn_fused_supported(C: int, n: int) -> bool:
+    return bool(_lib.load().uwir_ffn_fused_supported(C, n))
+
+
+def ffn_permute_w2(w2: torch.Tensor) -> torch.Tensor:
+    """ffn.2.weight [C, 2C] with the columns of every 32-block in the order uwir_ffn_fused reads them (include/uwir.h)."""
+    K = w2.shape[1]
+    pos = torch.arange(K, device=w2.device)
+    s, q, e = pos // 32, (pos // 8) % 4, pos % 8
+    src = 32 * s + torch.where(e < 4, 4 * q + e, 16 + 4 * q + e - 4)
+    return w2[:, src].contiguous()
+
+
+def ffn_fused(x: torch.Tensor, w0b: torch.Tensor, bias0b: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, B: int, n: int,
+              C: int, out: torch.Tensor) -> None:
+    """out = W2 gelu(W0_b x + bias0_b) + b2 + x in one launch (wtb.py:117-124, bf16 mode): include/uwir.h."""
+    _f32(bias0b, b2)
+    bf = torch.bfloat16
+    if x.dtype != bf or w0b.dtype != bf or w2p.dtype != bf or out.dtype != bf:
+        raise ValueError("ffn_fused: x, w0b, w2p and out must be bf16")
+    if tuple(w0b.shape) != (B, 2 * C, C) or w0b.stride(2) != 1 or w0b.stride(1) != C:
+        raise ValueError("ffn_fused: w0b must be [B, 2C, C] with dense panels")
+    if tuple(w2p.shape) != (C, 2 * C) or not w2p.is_contiguous() or tuple(bias0b.shape) != (B, 2 * C) or not bias0b.is_contiguous():
+        raise ValueError("ffn_fused: w2p must be a contiguous [C, 2C] and bias0b a contiguous [B, 2C]")
+    if x.shape[0] != B * n or out.shape[0] != B * n or x.shape[1] < C or out.shape[1] < C:
+        raise ValueError("ffn_fused: x and out must have B * n rows of at least C channels")
+    lib = _lib.load()
+    _lib.check(lib.uwir_ffn_fused(_p(x), _ld(x), _p(w0b), w0b.stride(0), _p(bias0b), _p(w2p), _p(b2), B, n, C, _p(out), _ld(out),
+                                  _stream(x)), "ffn_fused")
+
+
 def ln2d_workspace_bytes(B: int, n: int, C_: int) -> int:
     return int(_lib.load().uwir_ln2d_workspace_bytes(B, n, C_))
 

@@ -71,6 +71,7 @@ class NAFNetWFIGate(nn.Module):
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
         self.fold_norms = True              # bf16: LayerNorm2d affines folded into per-image weight panels (see _wfi_block)
         self.fuse_gate = True               # bf16: WFIGate + idwt2 in one launch (ops.gate_idwt); False keeps the three launches
+        self.fuse_ffn = True                # bf16, folded norms: ffn.0 -> GELU -> ffn.2 + residual in one launch (ops.ffn_fused)
         self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
 
     # ------------------------------------------------------------------ parameters
@@ -169,6 +170,8 @@ class NAFNetWFIGate(nn.Module):
             b["ca_w1"], b["ca_b1"] = sd[h + "channel_attn.net.2.weight"].to(f32).contiguous(), vec(sd[h + "channel_attn.net.2.bias"])
             b["ffn0_w"], b["ffn0_b"] = mat(sd[h + "ffn.0.weight"]), vec(sd[h + "ffn.0.bias"])
             b["ffn2_w"], b["ffn2_b"] = mat(sd[h + "ffn.2.weight"]), vec(sd[h + "ffn.2.bias"])
+            if wdt == torch.bfloat16:
+                b["ffn2_wp"] = ops.ffn_permute_w2(b["ffn2_w"])     # k order of the fused FFN kernel (csrc/ffn.hip)
             l = p + "lf_block."
             b["lnorm_g"], b["lnorm_b"] = vec(sd[l + "norm.norm.weight"]), vec(sd[l + "norm.norm.bias"])
             b["lnorm_ss"] = add_cond(sd[l + "norm.linear.weight"], sd[l + "norm.linear.bias"])
@@ -361,20 +364,25 @@ class NAFNetWFIGate(nn.Module):
         a2, s2 = small("a2", Cw), small("s2", Cw)
         o, ln_ = bp["norm2_ss"]
         ops.ln2d_affine(x1, B, n, Cw, _EPS, bp["norm2_g"], bp["norm2_b"], cond_all[:, o:o + ln_], a2, s2, None, None, ws)
-        hidden = buf("ffh", 2 * Cw, adt)
+        hf_out = hf  # hf is dead after the proj GEMM: reuse its storage
+        fused_ffn = fold and self.fuse_ffn and ops.ffn_fused_supported(Cw, n)
+        hidden = None if fused_ffn else buf("ffh", 2 * Cw, adt)
         if fold:
             wb = self._buf(tg + "wb_ffn", B * 2 * Cw, Cw, adt, dev).view(B, 2 * Cw, Cw)
             bbf = small("bb_ffn", 2 * Cw)
             ops.fold_affine_weights(bp["ffn0_w32"], a2, s2, bp["ffn0_b"], wb, bbf)
-            ops.conv_gemm(x1, wb, hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, batch_bias=bbf, act=ops.ACT_GELU, w_batched=True)
+            if fused_ffn:   # ffn.0 -> GELU -> ffn.2 + residual in one launch: the [M, 2Cw] hidden rows never reach HBM
+                ops.ffn_fused(x1, wb, bbf, bp["ffn2_wp"], bp["ffn2_b"], B, n, Cw, hf_out)
+            else:
+                ops.conv_gemm(x1, wb, hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, batch_bias=bbf, act=ops.ACT_GELU, w_batched=True)
         elif bf:
             ops.affine_cast(x1, B, n, Cw, a2, s2, xn)
             ops.conv_gemm(xn, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, bias=bp["ffn0_b"], act=ops.ACT_GELU)
         else:
             ops.conv_gemm(x1, bp["ffn0_w"], hidden, B=B, H=h, W=w, C_=Cw, N=2 * Cw, a_scale=a2, a_shift=s2,
                           bias=bp["ffn0_b"], act=ops.ACT_GELU)
-        hf_out = hf  # hf is dead after the proj GEMM: reuse its storage
-        ops.conv_gemm(hidden, bp["ffn2_w"], hf_out, B=B, H=h, W=w, C_=2 * Cw, N=Cw, bias=bp["ffn2_b"], res=x1)
+        if not fused_ffn:
+            ops.conv_gemm(hidden, bp["ffn2_w"], hf_out, B=B, H=h, W=w, C_=2 * Cw, N=Cw, bias=bp["ffn2_b"], res=x1)
 
         if side is not None:
             torch.cuda.current_stream(dev).wait_event(sffb_done)
