@@ -111,6 +111,13 @@ def _op_work(name: str, a: tuple, k: dict):
     if name == "affine_cast":
         x, B, n, C, out = a[0], a[1], a[2], a[3], a[6]
         return "affine_cast (norm materialised)", "byte", float(B * n * C) * (_esz(x) + _esz(out))
+    if name == "gate_idwt":
+        gi, hf, B, h, w, C, out = a[0], a[5], a[6], a[7], a[8], a[9], a[10]
+        # gate row + hf row in, alpha + four output pixels out (csrc/gate.hip)
+        return "WFIGate + idwt2 (fused)", "byte", float(B * h * w) * (gi.shape[1] * 4 + 3 * C * _esz(hf) + C * 4 + 4 * C * _esz(out))
+    if name == "ffn_fused":
+        x, B, n, C, out = a[0], a[5], a[6], a[7], a[8]
+        return "WTB FFN (fused ffn.0 -> GELU -> ffn.2 + residual)", "flop", 2.0 * B * n * C * (2 * C) * 2
     if name in ("sde_posterior_step", "sde_euler_step"):
         return "fused SDE step", "byte", 20.0 * a[0].numel()
     if name == "linear_attention":

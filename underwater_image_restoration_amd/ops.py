@@ -602,6 +602,7 @@ def _census_wrap(name: str, fn):
 
 for _n in ("dwt2", "idwt2", "ln2d_affine", "conv_gemm", "dwconv_ms", "flash_attn", "fft2_amp_phase", "ifft2_polar_add",
            "affine_cast", "stem_conv3x3", "head_conv3x3", "sde_euler_step", "sde_posterior_step", "linear_attention",
-           "ln_rows", "groupnorm_affine", "geglu", "linattn_block", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear"):
+           "ln_rows", "groupnorm_affine", "geglu", "linattn_block", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear",
+           "gate_idwt", "ffn_fused", "fold_affine_weights"):
     globals()[_n] = _census_wrap(_n, globals()[_n])
 del _n
