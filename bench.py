@@ -560,9 +560,9 @@ def dominant_roofline(args, timings):
     Bk, hd = dom[0][0][1], dom[0][0][4]
     dom = [ms for tag, ms in dom if tag[1] == Bk]
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
+    tj = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")  # rocprofv3 --pmc passes of this same command
     if not os.path.exists(tj):
-        tj = os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
     if os.path.exists(tj) and args.workload == "student" and args.batch == 16 and args.size == 256 and args.precision == "bf16":
         with open(tj) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
