@@ -471,6 +471,19 @@ int uwir_guided_filter(const float* input, const float* guidance, int H, int W, 
 size_t uwir_multi_scale_retinex_workspace_bytes(int C, int H, int W);
 int uwir_multi_scale_retinex(const float* x, int C, int H, int W, const double* sigmas, int nsig, float* out,
                              void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+/* ---- the OpenCV-backed operators and scores of the RL adapter (PARITY UNPINNED: cv2 is absent from the build container, so
+ * no vector of the reference could be generated; csrc/enhance_cv.hip restates OpenCV's documented arithmetic, the tests
+ * compare against an independent numpy restatement in oracle/enhance_ref.py).  One workspace size serves all three
+ * (tiles = the CLAHE grid, 8 x 8 for the other two), 256-byte aligned.
+ * rl/uiep_cwgr_ops.py:24-35 histogram_equalization: (C, H, W) fp32 image, C <= 3 -> equalised image (uint8 levels / 255).
+ * rl/uiep_cwgr_ops.py:38-44 clahe_equalization: (3, H, W) RGB -> 8-bit Lab -> CLAHE(clip_limit, tiles) on L -> RGB.
+ * rl/uiqm_uciqe.py:24-65: out3 (DEVICE doubles) = compute_uism, compute_uiconm, compute_uciqe of a (3, H, W) image. */
+size_t uwir_cv_workspace_bytes(int H, int W, int tiles_y, int tiles_x);
+int uwir_histogram_equalization(const float* img, int C, int H, int W, float* out, void* workspace, size_t workspace_bytes,
+                                uwir_stream_t stream);
+int uwir_clahe_equalization(const float* img, int H, int W, float clip_limit, int tiles_y, int tiles_x, float* out,
+                            void* workspace, size_t workspace_bytes, uwir_stream_t stream);
+int uwir_cv_scores(const float* img, int H, int W, double* out3, void* workspace, size_t workspace_bytes, uwir_stream_t stream);
 /* State features of rl/infer_adapt.py:62-68 build_state on a (C, H, W) image, written to 4 DEVICE doubles:
  * out4[0] = compute_uicm (rl/uiqm_uciqe.py:13-21; on the uint8-quantised image, C must be 3, else NaN),
  * out4[1], out4[2] = mean and unbiased std over every element, out4[3] = compute_sharpness (:52-59). */

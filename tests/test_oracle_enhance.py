@@ -63,3 +63,41 @@ def test_state_features():
     assert abs(ref.compute_sharpness(img[None].double()) - float(G["sharpness_f64"])) <= 1e-12
     m, s = ref.histogram_stats(img[None])
     assert abs(m - float(G["hist_mean"])) <= 1e-7 and abs(s - float(G["hist_std"])) <= 1e-7
+
+
+# ---- the OpenCV-backed functions: PARITY UNPINNED (cv2 is absent here).  What CAN be checked on the CPU: the restatement
+# against the widely published 8-bit Lab values of the sRGB primaries, the reference's numpy hist-eq arithmetic on a case
+# whose answer is known in closed form, and structural properties of CLAHE.
+def test_lab8_known_answers_and_round_trip():
+    prim = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    lab = ref.rgb_to_lab8(prim)[0]
+    # cv2.cvtColor(..., COLOR_RGB2LAB) of white / red / green / blue / black / mid grey as OpenCV's documentation and
+    # countless posts quote them
+    assert lab.tolist() == [[255, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [0, 128, 128], [137, 128, 128]]
+    g = np.random.default_rng(0)
+    grey = np.repeat(g.integers(0, 256, (16, 16, 1), dtype=np.uint8), 3, axis=2)
+    back = ref.lab8_to_rgb8(ref.rgb_to_lab8(grey))
+    assert int(np.abs(back.astype(int) - grey.astype(int)).max()) <= 1          # greys survive the 8-bit round trip
+
+
+def test_histogram_equalization_closed_form():
+    # every level 0..255 exactly four times: cdf = 4 (v + 1), (cdf - 4) * 255 / (1020 + 1e-6) in float64, truncated
+    v = np.repeat(np.arange(256, dtype=np.float32), 4).reshape(32, 32)
+    img = torch.from_numpy((v + 0.5) / 255.0)[None].repeat(3, 1, 1)
+    out = ref.histogram_equalization(img)
+    lev = np.rint(out.numpy() * 255).astype(int)[0]
+    expect = np.floor((4.0 * v.astype(np.float64)) * 255 / (1020 + 1e-6)).astype(int)      # = max(v - 1, 0): the 1e-6 bites
+    assert np.array_equal(lev, expect) and out.shape == img.shape
+
+
+def test_clahe_properties():
+    g = np.random.default_rng(1)
+    plane = g.integers(0, 256, (40, 56), dtype=np.uint8)
+    out = ref.clahe_u8(plane, 2.0, (8, 8))                      # 56 / 8 and 40 / 8 exact; no padding
+    assert out.shape == plane.shape and out.dtype == np.uint8
+    # a huge clip limit on one tile is plain equalisation: LUT = round(cdf * 255 / area), monotone in the level
+    one = ref.clahe_u8(plane, 1e9, (1, 1))
+    cdf = np.cumsum(np.bincount(plane.ravel(), minlength=256))
+    assert np.array_equal(one, np.clip(np.rint(cdf.astype(np.float32) * np.float32(255) / np.float32(plane.size)), 0, 255).astype(np.uint8)[plane])
+    # padded case (45 x 70 on an 8 x 8 grid) runs and keeps the shape
+    assert ref.clahe_u8(g.integers(0, 256, (45, 70), dtype=np.uint8), 2.0).shape == (45, 70)

@@ -119,6 +119,10 @@ _SIGS = {
     "uwir_teacher_heads_workspace_bytes": (sz, [ci, ci, ci]),
     "uwir_teacher_heads": (ci, [C.POINTER(TeacherArgs), vp]),
     "uwir_guided_crf": (ci, [C.POINTER(TeacherArgs), vp, vp, vp]),
+    "uwir_cv_workspace_bytes": (sz, [ci, ci, ci, ci]),
+    "uwir_histogram_equalization": (ci, [vp, ci, ci, ci, vp, vp, sz, vp]),
+    "uwir_clahe_equalization": (ci, [vp, ci, ci, cf, ci, ci, vp, vp, sz, vp]),
+    "uwir_cv_scores": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "uwir_gamma_correction": (ci, [vp, vp, sz, cf, vp]),
     "uwir_lf_hf_mix": (ci, [vp, vp, C.c_double, vp, sz, vp]),
     "uwir_wavelet_denoise_workspace_bytes": (sz, [ci, ci, ci]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libuwir_hip.so")
 SOURCES = ["elementwise.hip", "dwconv.hip", "gemm.hip", "gemm_wide.hip", "gemm_wide288.hip", "gate.hip", "ffn.hip", "attention.hip", "fft.hip", "tokens.hip", "unet.hip", "linattn.hip", "metrics.hip",
-           "teacher.hip", "enhance.hip"]
+           "teacher.hip", "enhance.hip", "enhance_cv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it every softmax /
 # epilogue touch of an accumulator costs a v_accvgpr_read/write pair.
