@@ -39,6 +39,8 @@ def timeit(f, reps):
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+    if os.environ.get("UWIR_EXP_LIB"):      # an experimental build of the library (ablations under tools/exp)
+        _lib.LIB_PATH = os.path.abspath(os.environ["UWIR_EXP_LIB"])
     lib = _lib.load()
     B = 8
     shapes = [SHAPES[int(i)] for i in sys.argv[3].split(",")] if len(sys.argv) > 3 else SHAPES

@@ -2,7 +2,18 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_conv
-mkdir -p $O
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $O/p1 -o p1 --output-format csv -- python3 $R/tools/bench_conv.py 5 0 1,15 > $O/p1.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM -d $O/p2 -o p2 --output-format csv -- python3 $R/tools/bench_conv.py 5 0 1,15 > $O/p2.log 2>&1
-ls -R $O | head -30
+SH=${1:-10,14}
+rm -rf $O; mkdir -p $O
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $O/p1 -o p1 --output-format csv -- python3 $R/tools/bench_conv.py 5 0 $SH > $O/p1.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM -d $O/p2 -o p2 --output-format csv -- python3 $R/tools/bench_conv.py 5 0 $SH > $O/p2.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob("$O/p*/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "conv3x3" not in k: continue
+        a = acc[(k[:60], r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    for (k, c), (v, n) in sorted(acc.items()):
+        print(k, c, round(v / n), n)
+PY

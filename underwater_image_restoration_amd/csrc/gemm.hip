@@ -1100,21 +1100,44 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
     }
     const int w_rd = fr * 64 + (fq ^ hc_swz(fr)) * 16;
 
-    auto compute = [&](auto grp_tag, const char* sa, const char* sw) {
+    // The three taps of a stage are software-pipelined by hand: tap t + 1's fragments are read (into the other half of
+    // fa / fb) between tap t's first MFMAs -- one ds_read_b128 behind each MFMA, pinned with sched_group_barrier -- so
+    // that only the first tap of a stage waits for LDS.  Left to itself the scheduler put most reads directly in front
+    // of the MFMA that consumes them (lgkmcnt(0) a dozen times per stage), which at two waves per SIMD showed: without
+    // any DMA in the loop the kernel still ran at 45 % of the MFMA rate.
+    auto compute = [&](auto grp_tag, const char* sa, const char* sw, auto&& refill) {
         constexpr int grp = decltype(grp_tag)::value;
-#pragma unroll
-        for (int tapl = 0; tapl < HC_TG; ++tapl) {
-            bf16x8 fa[TM], fb[TN];
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto read_tap = [&](int tapl, int h) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + grp) % KV] + (i + grp) * (PWL * 64));
+                fa[h][i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[tapl][(i + grp) % KV] + (i + grp) * (PWL * 64));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sw + w_rd + (tapl * BN + j * 16) * 64);
+            for (int j = 0; j < TN; ++j) fb[h][j] = *reinterpret_cast<const bf16x8*>(sw + w_rd + (tapl * BN + j * 16) * 64);
+        };
+        read_tap(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        refill();                                  // the stage's DMA issue (slow: ~100 cycles each) under the first reads' latency
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tapl = 0; tapl < HC_TG; ++tapl) {
+            const int h = tapl & 1;
+            if (tapl + 1 < HC_TG) read_tap(tapl + 1, h ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
+            if (tapl + 1 < HC_TG) {
+#pragma unroll
+                for (int k = 0; k < TM + TN; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
         }
     };
 
@@ -1139,12 +1162,16 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(GemmP p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+#if !defined(CD_ABL) || CD_ABL != 3
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        if (s + NS - 1 < S) issue_w(s + NS - 1);
-        if (grp == 0 && !last) issue_a(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(grp_tag, smem + (c & 1) * A_BYTES, smem + 2 * A_BYTES + (s % NS) * W_BYTES);
+        compute(grp_tag, smem + (c & 1) * A_BYTES, smem + 2 * A_BYTES + (s % NS) * W_BYTES, [&]() {
+#if !defined(CD_ABL) || CD_ABL != 2
+            if (s + NS - 1 < S) issue_w(s + NS - 1);
+            if (grp == 0 && !last) issue_a(c + 1);
+#endif
+        });
         __builtin_amdgcn_sched_barrier(0);
     };
 
