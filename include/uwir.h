@@ -267,6 +267,13 @@ int uwir_ifft2_polar_add(const float* amp, const float* phase, int ld_in, const 
 int uwir_bilinear_nchw_to_nhwc(const float* src, int B, int M, int hs, int ws, float* dst, int ldd, int hd, int wd,
                                uwir_stream_t stream);
 
+/* ---- F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False), S/model.py:150-151 --
+ * The decoder's resize of an up-sampled map to its skip's size, taken whenever a level's side is odd.
+ * src rows [B,hs,ws,C] (pixel stride ld_src) -> dst rows [B,hd,wd,C] (pixel stride ldd), both of dtype (fp32 or bf16);
+ * C and both strides multiples of 4. */
+int uwir_bilinear_rows(const void* src, int ld_src, int B, int hs, int ws, int C, void* dst, int ldd, int hd, int wd,
+                       int dtype, uwir_stream_t stream);
+
 /* ---- S/model.py:81,133 stem: Conv2d(Cin,Cout,3,padding=1) reading the NCHW input image -------
  * w repacked [3,3,Cin,Cout]; out NHWC rows of out_dtype (bf16 needs Cin <= 4, Cout % 16 == 0).  Cout % 4 == 0. */
 int uwir_stem_conv3x3(const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout,

@@ -17,6 +17,11 @@ STUDENT_CASES = {
     # V1 teacher style cond (20), no masks, narrow net (head_dim 4/8/16)
     "narrow": dict(base_channels=16, blocks_per_level=1, cond_dim=20, num_masks=0, num_deg=5, batch=2, H=64, W=64,
                    mask_hw=(7, 7), wseed=2, xseed=5, taps=_TAPS),
+    # even sides whose deeper levels are odd: 38 -> 19 -> (dwt2 drops a row: 18) -> 9 -> (8), 44 -> 22 -> 11 -> (10).  The
+    # first block of a stage shrinks its odd input to the even size below it (dwt_fft.py:38 is a stride-2 valid conv) and the
+    # decoder resizes the up-sampled map to the skip's size (model.py:150-151).  FFT lines of 19 / 11 / 9 / 5 / 4 bins.
+    "evenodd": dict(base_channels=16, blocks_per_level=2, cond_dim=20, num_masks=3, num_deg=5, batch=2, H=38, W=44,
+                    mask_hw=(7, 7), wseed=6, xseed=17, taps=_TAPS),
 }
 
 DACLIP_CASES = {

@@ -451,6 +451,9 @@ if __name__ == "__main__":
     if "student" in which:
         for name, cfg in STUDENT_CASES.items():
             student_case(name, cfg)
+    for w in which:                 # one case only: student:NAME
+        if w.startswith("student:"):
+            student_case(w[8:], STUDENT_CASES[w[8:]])
     if "student_big" in which:      # not in the default set: minutes of CPU time and ~25 GB of RAM (fp64 CFC scores)
         for name, cfg in STUDENT_BIG_CASES.items():
             student_case(name, cfg)

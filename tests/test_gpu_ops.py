@@ -446,6 +446,24 @@ def test_bilinear(ops):
         assert float(dst[:, :4].min()) == 5.0 and float(dst[:, 14:].min()) == 5.0
 
 
+def test_bilinear_rows(ops):
+    """The decoder's resize to its skip's size (model.py:150-151) on NHWC rows, fp32 and bf16, strided source and
+    destination, against F.interpolate on the CPU (fp32: 1e-6; bf16: inputs exact in bf16, one rounding of the result)."""
+    g = torch.Generator().manual_seed(12)
+    for (hs, ws_, hd, wd, C) in ((16, 20, 18, 22, 32), (36, 40, 38, 44, 16), (4, 4, 4, 4, 8), (2, 2, 7, 3, 4)):
+        src = torch.rand(2, C, hs, ws_, generator=g).bfloat16().float()
+        ref = F.interpolate(src, size=(hd, wd), mode="bilinear", align_corners=False)
+        for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 4e-3)):
+            rows = torch.zeros(2 * hs * ws_, C + 8, device="cuda", dtype=dt)
+            rows[:, 4:4 + C] = src.permute(0, 2, 3, 1).reshape(-1, C).to(dt).cuda()
+            dst = torch.full((2 * hd * wd, 2 * C), 5.0, device="cuda", dtype=dt)
+            ops.bilinear_rows(rows[:, 4:4 + C], 2, hs, ws_, C, dst[:, C:], hd, wd)
+            assert err(from_rows(dst[:, C:].float(), 2, hd, wd), ref) < tol
+            assert float(dst[:, :C].float().min()) == 5.0
+    with pytest.raises(ValueError):
+        ops.bilinear_rows(torch.zeros(8, 6, device="cuda"), 2, 2, 2, 6, torch.zeros(8, 6, device="cuda"), 2, 2)
+
+
 def test_stem_and_head(ops):
     g = torch.Generator().manual_seed(11)
     b, h, w = 2, 12, 20

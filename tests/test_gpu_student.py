@@ -70,7 +70,7 @@ def test_student_fp32_matches_oracle_and_golden(name):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("name", ["full32", "rect"])
+@pytest.mark.parametrize("name", ["full32", "rect", "evenodd"])
 def test_student_bf16_psnr(name):
     """bf16 mode against the reference's own fp64 output: PSNR(build, ref) >= 60 dB at the golden sizes (measured
     79-80 dB), and north_star's "PSNR delta <= 0.05 dB" against a pseudo ground truth DERIVED FROM the reference output
@@ -97,8 +97,10 @@ def test_student_api_errors():
     m = NAFNetWFIGate(cond_dim=8).cuda()
     with pytest.raises(ValueError, match="Condition vector z_d must be provided."):
         m(torch.zeros(1, 3, 16, 16, device="cuda"), None)
-    with pytest.raises(ValueError):
-        m(torch.zeros(1, 3, 20, 16, device="cuda"), torch.zeros(1, 8, device="cuda"))
+    with pytest.raises(ValueError, match="must be even"):     # the reference fails here too (out + residual, model.py:161)
+        m(torch.zeros(1, 3, 21, 16, device="cuda"), torch.zeros(1, 8, device="cuda"))
+    with pytest.raises(ValueError, match="too small"):
+        m(torch.zeros(1, 3, 4, 16, device="cuda"), torch.zeros(1, 8, device="cuda"))
 
 
 @pytest.mark.parametrize("hw", [(48, 80), (120, 72)])

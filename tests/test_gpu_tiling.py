@@ -88,5 +88,7 @@ def test_any_size_restorer_pads_and_crops():
     assert torch.equal(out, ref)
     xa, za, ma = synth_student_inputs(1, 48, 80, 20, 10, mask_hw=(7, 7), seed=6)
     assert torch.equal(anyr(xa.cuda(), za.cuda(), ma.cuda()), TiledRestorer(model, tile=32, halo=8, max_batch=8)(xa.cuda(), za.cuda(), ma.cuda()))
+    xe, ze, me = synth_student_inputs(1, 20, 28, 20, 10, mask_hw=(7, 7), seed=7)     # even, within one tile: the model itself
+    assert torch.equal(anyr(xe.cuda(), ze.cuda(), me.cuda()), model(xe.cuda(), ze.cuda(), me.cuda())[0])
     with pytest.raises(ValueError):
         anyr(torch.rand(1, 3, 2, 50).cuda(), z[:1].cuda(), m[:1].cuda())

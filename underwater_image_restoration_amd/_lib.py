@@ -84,6 +84,7 @@ _SIGS = {
     "uwir_fft2_amp_phase": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, sz, vp]),
     "uwir_ifft2_polar_add": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, sz, vp]),
     "uwir_bilinear_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
+    "uwir_bilinear_rows": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "uwir_stem_conv3x3": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_head_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "uwir_stem_conv3x3_win": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp]),

@@ -740,6 +740,56 @@ __device__ __forceinline__ bool window_core_ok(const uwir_window& w, int T) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bilinear resize of feature ROWS (NHWC -> NHWC, align_corners=False): the decoder's F.interpolate of an up-sampled map to
+// its skip's size (S/model.py:150-151), which the reference takes whenever a level's side is odd.  One thread per pixel and
+// 4-channel group; same source-index rule and product order as bilinear_kernel below.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_rows_kernel(const T* __restrict__ src, int lds_, int B, int hs, int ws, int C,
+                                                            T* __restrict__ dst, int ldd, int hd, int wd, float sy, float sx) {
+    const int c4 = C / 4;
+    const size_t total = (size_t)B * hd * wd * c4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        const size_t p = i / c4;
+        const int ox = (int)(p % wd);
+        const size_t q = p / wd;
+        const int oy = (int)(q % hd), b = (int)(q / hd);
+        const float fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)fy, hs - 1), x0 = min((int)fx, ws - 1);
+        const int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const T* s = src + (size_t)b * hs * ws * lds_ + c;
+        const float4 v00 = load4(s + ((size_t)y0 * ws + x0) * lds_), v01 = load4(s + ((size_t)y0 * ws + x1) * lds_);
+        const float4 v10 = load4(s + ((size_t)y1 * ws + x0) * lds_), v11 = load4(s + ((size_t)y1 * ws + x1) * lds_);
+        float4 o;
+        o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        store4(dst + p * ldd + c, o);
+    }
+}
+
+extern "C" int uwir_bilinear_rows(const void* src, int lds_, int B, int hs, int ws, int C, void* dst, int ldd, int hd, int wd,
+                                  int dtype, uwir_stream_t stream) {
+    UWIR_CHECK(src && dst, "bilinear_rows: null pointer");
+    UWIR_CHECK(B > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && C > 0 && C % 4 == 0 && lds_ >= C && ldd >= C &&
+                   lds_ % 4 == 0 && ldd % 4 == 0, "bilinear_rows: bad shape (C and the pixel strides must be multiples of 4)");
+    UWIR_CHECK(dtype == UWIR_F32 || dtype == UWIR_BF16, "bilinear_rows: dtype must be fp32 or bf16");
+    const size_t total = (size_t)B * hd * wd * (C / 4);
+    const float sy = (float)hs / (float)hd, sx = (float)ws / (float)wd;
+    if (dtype == UWIR_BF16)
+        hipLaunchKernelGGL(bilinear_rows_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, lds_, B, hs, ws, C, (bf16_t*)dst, ldd, hd, wd, sy, sx);
+    else
+        hipLaunchKernelGGL(bilinear_rows_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)src, lds_, B, hs, ws, C, (float*)dst, ldd, hd, wd, sy, sx);
+    UWIR_LAUNCH_CHECK("bilinear_rows");
+    return UWIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // bilinear resize (align_corners=False, no antialias), NCHW source -> NHWC destination columns
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ src, int B, int M, int hs, int ws,

@@ -359,6 +359,16 @@ def bilinear_nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, hd: int, wd: int
     _lib.check(lib.uwir_bilinear_nchw_to_nhwc(_p(src), B, M, hs, ws, _p(dst), _ld(dst), hd, wd, _stream(src)), "bilinear")
 
 
+def bilinear_rows(src: torch.Tensor, B: int, hs: int, ws: int, C: int, dst: torch.Tensor, hd: int, wd: int) -> None:
+    """F.interpolate(x, size=(hd, wd), mode="bilinear", align_corners=False) on NHWC rows: src [B*hs*ws, >= C] -> dst
+    [B*hd*wd, >= C] of the same dtype (fp32 or bf16) -- the decoder's resize to its skip's size (S/model.py:150-151)."""
+    if src.dtype != dst.dtype or src.shape[0] < B * hs * ws or dst.shape[0] < B * hd * wd:
+        raise ValueError("bilinear_rows: src / dst dtype or row count mismatch")
+    lib = _lib.load()
+    _lib.check(lib.uwir_bilinear_rows(_p(src), _ld(src), B, hs, ws, C, _p(dst), _ld(dst), hd, wd, _dt(src), _stream(src)),
+               "bilinear_rows")
+
+
 def stem_conv3x3(x_nchw: torch.Tensor, w, bias, out: torch.Tensor) -> None:
     _f32(x_nchw, w, bias)
     lib = _lib.load()

@@ -8,8 +8,8 @@ MFMA everywhere, "bf16" bf16 MFMA for GEMMs/attention with fp32 accumulation, no
 
 Internally everything is NHWC (= torch channels_last memory) and runs through the C ABI in
 ``include/uwir.h``; this file only owns buffers, weight repacking and launch order.
-Restrictions vs the reference: H and W must be multiples of 2**num_levels (the reference's
-bilinear fallback for odd sizes, model.py:150-151, is not implemented), CUDA(HIP) tensors only.
+Sizes: any even H and W, as in the reference (odd deeper levels shrink inside a stage's first block and the decoder
+resizes to the skip, model.py:150-151; an odd H or W fails in the reference as well).  CUDA(HIP) tensors only.
 """
 from __future__ import annotations
 
@@ -293,7 +293,8 @@ class NAFNetWFIGate(nn.Module):
     # ------------------------------------------------------------------ one WFI block
     def _wfi_block(self, bp: dict, x_in: torch.Tensor, B: int, h2: int, w2: int, cond_all: torch.Tensor,
                    gate_in: torch.Tensor, out: torch.Tensor, lvl: int, taps: Optional[dict]) -> torch.Tensor:
-        """x_in: [B*h2*w2, ld] view with C channels; writes out ([B*h2*w2, ld'] view); returns alpha [B,h,w,C]."""
+        """x_in: [B*h2*w2, ld] view with C channels; writes out ([B*2h*2w, ld'] view, h = h2 // 2, w = w2 // 2: an odd
+        input side loses its last row / column in dwt2, dwt_fft.py:38); returns alpha [B,h,w,C]."""
         Cc = bp["C"]
         Cw = 3 * Cc
         h, w = h2 // 2, w2 // 2
@@ -420,7 +421,7 @@ class NAFNetWFIGate(nn.Module):
             nchw = lambda t, c: t[:, :c].reshape(B, h, w, c).permute(0, 3, 1, 2).float().clone()  # noqa: E731
             taps.update(hf=nchw(hf_out, Cw), lf=nchw(lf, Cc), t_out=nchw(gate_in, Cc),
                         f_out=nchw(gate_in[:, Cc:], Cc), merged=nchw(merged, Cc), alpha=alpha.permute(0, 3, 1, 2),
-                        out=out[:, :Cc].reshape(B, h2, w2, Cc).permute(0, 3, 1, 2).float().clone(),
+                        out=out[:, :Cc].reshape(B, 2 * h, 2 * w, Cc).permute(0, 3, 1, 2).float().clone(),
                         wtb=dict(qkv_base=nchw(qkv_base, 3 * Cw), att=nchw(att, Cw),
                                  x1=nchw(x1, Cw)),
                         sffb=dict(spatial=nchw(spatial, Cc), freq=None))
@@ -452,9 +453,21 @@ class NAFNetWFIGate(nn.Module):
             B, H, W = int(win.shape[0]), T, T
             if cond.shape[0] != B:
                 raise ValueError("window mode: cond needs one row per window")
-        div = 2 ** self.num_levels
-        if H % div or W % div:
-            raise ValueError(f"H and W must be multiples of {div} for this build (got {H}x{W})")
+        # Level geometry.  dwt2 is a stride-2 valid conv (dwt_fft.py:38): the first block of a stage turns an odd input side
+        # into the even side below it, everything after it at that level (later blocks, the skip, the down-sampling conv) has
+        # that even size, and the decoder resizes its up-sampled map to the skip's size when they differ (model.py:150-151).
+        # Odd H or W itself fails in the reference too: the head's output is one pixel short of the residual (model.py:161).
+        if H % 2 or W % 2:
+            raise ValueError(f"H and W must be even (got {H}x{W}): with an odd side the reference's final "
+                             "`out + residual` (model.py:161) adds tensors of different sizes")
+        size_in, size = [], []
+        hi, wi = H, W
+        for lvl in range(self.num_levels):
+            if hi < 2 or wi < 2:
+                raise ValueError(f"a {H}x{W} image is too small for {self.num_levels} levels")
+            size_in.append((hi, wi))
+            size.append((hi // 2 * 2, wi // 2 * 2))
+            hi, wi = size[-1][0] // 2, size[-1][1] // 2
         if (masks is None) != (self.num_masks == 0):
             raise ValueError("masks must be given iff the model was built with num_masks > 0")
         if masks is not None and masks.shape[1] != self.num_masks:
@@ -475,7 +488,7 @@ class NAFNetWFIGate(nn.Module):
         # per level: gate input [t | f | masks(resized) | 0-pad], feature / concat buffers
         gate_in, feat, cat = [], [], []
         for lvl in range(L):
-            Hl, Wl = H >> lvl, W >> lvl
+            (Hi, Wi), (Hl, Wl) = size_in[lvl], size[lvl]
             h, w = Hl // 2, Wl // 2
             gi = self._buf(f"gate_in{lvl}", B * h * w, 2 * ch[lvl] + Mp, f32, dev, zero=True)
             if masks is not None and win is not None:
@@ -484,7 +497,8 @@ class NAFNetWFIGate(nn.Module):
                 ops.bilinear_nchw_to_nhwc(masks, gi[:, 2 * ch[lvl]:2 * ch[lvl] + Mk], h, w)
             gate_in.append(gi)
             # (bf16 mode: the feature stream between blocks, the skip concats and the sub-bands are bf16 rows)
-            feat.append([self._buf(f"feat{lvl}_{i}", B * Hl * Wl, ch[lvl], pk["adt"], dev) for i in range(2)])
+            # (feat rows: the stage's input size; everything a block writes has the even size and uses the leading rows)
+            feat.append([self._buf(f"feat{lvl}_{i}", B * Hi * Wi, ch[lvl], pk["adt"], dev) for i in range(2)])
             cat.append(self._buf(f"cat{lvl}", B * Hl * Wl, 2 * ch[lvl], pk["adt"], dev) if lvl < L - 1 else None)
 
         if win is not None:
@@ -495,16 +509,18 @@ class NAFNetWFIGate(nn.Module):
             taps["stem"] = feat[0][0].reshape(B, H, W, ch[0]).permute(0, 3, 1, 2).float().clone()
         alphas: List[torch.Tensor] = []
 
-        def run_stage(prefix: str, lvl: int, cur: torch.Tensor, final_out: Optional[torch.Tensor]) -> torch.Tensor:
-            Hl, Wl = H >> lvl, W >> lvl
+        def run_stage(prefix: str, lvl: int, cur: torch.Tensor, final_out: Optional[torch.Tensor],
+                      in_size: Tuple[int, int]) -> torch.Tensor:
+            Hl, Wl = size[lvl]
             for bi in range(self.blocks_per_level):
                 last = bi == self.blocks_per_level - 1
                 if last and final_out is not None:
                     dst = final_out
                 else:
-                    dst = feat[lvl][1] if cur.data_ptr() == feat[lvl][0].data_ptr() else feat[lvl][0]
+                    dst = (feat[lvl][1] if cur.data_ptr() == feat[lvl][0].data_ptr() else feat[lvl][0])[:B * Hl * Wl]
                 bt = {} if taps is not None else None
-                a = self._wfi_block(pk["blocks"][f"{prefix}.blocks.{bi}."], cur, B, Hl, Wl, cond_all, gate_in[lvl],
+                hb, wb_ = in_size if bi == 0 else (Hl, Wl)     # only a stage's first block can see an odd side
+                a = self._wfi_block(pk["blocks"][f"{prefix}.blocks.{bi}."], cur, B, hb, wb_, cond_all, gate_in[lvl],
                                     dst, lvl, bt)
                 alphas.append(a.permute(0, 3, 1, 2))
                 if self.on_block is not None:
@@ -516,9 +532,9 @@ class NAFNetWFIGate(nn.Module):
 
         cur = feat[0][0]
         for lvl in range(L):
-            Hl, Wl = H >> lvl, W >> lvl
+            Hl, Wl = size[lvl]
             skip_view = cat[lvl][:, ch[lvl]:] if lvl < L - 1 else None  # encoder output lands in [x_up | skip]
-            cur = run_stage(f"encoder_stages.{lvl}", lvl, cur, skip_view)
+            cur = run_stage(f"encoder_stages.{lvl}", lvl, cur, skip_view, size_in[lvl])
             if lvl < L - 1:
                 nxt = feat[lvl + 1][0]
                 ops.conv_gemm(cur, pk[f"down{lvl}_w"], nxt, B=B, H=Hl, W=Wl, C_=ch[lvl], N=ch[lvl + 1], KH=2, KW=2,
@@ -526,7 +542,7 @@ class NAFNetWFIGate(nn.Module):
                 cur = nxt
         logits = None
         if self.num_degradation_types is not None:
-            Hb, Wb = H >> (L - 1), W >> (L - 1)
+            Hb, Wb = size[L - 1]
             gap = self._buf("gap", B, ch[-1], f32, dev)
             ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, Hb * Wb, ch[-1]) // 8, 1), torch.float64, dev)
             ops.ln2d_affine(cur, B, Hb * Wb, ch[-1], _EPS, None, None, None, None, None, gap, None, ws)
@@ -535,14 +551,19 @@ class NAFNetWFIGate(nn.Module):
             logits = torch.empty(B, self.num_degradation_types, dtype=f32, device=dev)
             ops.linear(dh, pk["dh_w1"], pk["dh_b1"], logits)
         for di, lvl in enumerate(reversed(range(L - 1))):
-            Hs, Ws = H >> (lvl + 1), W >> (lvl + 1)
-            # ConvTranspose2d(k=2,s=2) = GEMM + depth-to-space scatter into the left half of the concat buffer
-            ops.conv_gemm(cur, pk[f"up{di}_w"], cat[lvl][:, :ch[lvl]], B=B, H=Hs, W=Ws, C_=ch[lvl + 1], N=4 * ch[lvl],
+            (Hs, Ws), (Hl, Wl) = size[lvl + 1], size[lvl]
+            # ConvTranspose2d(k=2,s=2) = GEMM + depth-to-space scatter into the left half of the concat buffer -- or, when
+            # the skip is larger (an odd side below it), into a buffer of its own that is then resized (model.py:150-151)
+            direct = (2 * Hs, 2 * Ws) == (Hl, Wl)
+            up_dst = cat[lvl][:, :ch[lvl]] if direct else self._buf(f"up_tmp{lvl}", B * 4 * Hs * Ws, ch[lvl], pk["adt"], dev)
+            ops.conv_gemm(cur, pk[f"up{di}_w"], up_dst, B=B, H=Hs, W=Ws, C_=ch[lvl + 1], N=4 * ch[lvl],
                           bias=pk[f"up{di}_b"], store_mode=1)
-            fused = feat[lvl][0]
-            ops.conv_gemm(cat[lvl], pk[f"fuse{di}_w"], fused, B=B, H=H >> lvl, W=W >> lvl, C_=2 * ch[lvl], N=ch[lvl],
+            if not direct:
+                ops.bilinear_rows(up_dst, B, 2 * Hs, 2 * Ws, ch[lvl], cat[lvl][:, :ch[lvl]], Hl, Wl)
+            fused = feat[lvl][0][:B * Hl * Wl]
+            ops.conv_gemm(cat[lvl], pk[f"fuse{di}_w"], fused, B=B, H=Hl, W=Wl, C_=2 * ch[lvl], N=ch[lvl],
                           bias=pk[f"fuse{di}_b"])
-            cur = run_stage(f"decoder_stages.{di}", lvl, fused, None)
+            cur = run_stage(f"decoder_stages.{di}", lvl, fused, None, (Hl, Wl))
         fa, fs = self._buf("fn_a", B, ch[0], f32, dev), self._buf("fn_s", B, ch[0], f32, dev)
         ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, H * W, ch[0]) // 8, 1), torch.float64, dev)
         ops.ln2d_affine(cur, B, H * W, ch[0], _EPS, pk["fn_g"], pk["fn_b"], None, fa, fs, None, None, ws)

@@ -158,10 +158,11 @@ class AnySizeRestorer:
     1918, ...): reflect-pad bottom / right to the next multiple of 8, restore (through ``TiledRestorer`` when the padded
     frame is at least one tile), crop.  Aligned sizes pass straight through, bit-identical to the wrapped call.
 
-    Parity unpinned against the reference for the padded sizes: the reference runs such frames at their native size
-    (odd sub-band sizes inside its DWT) and resizes the result bilinearly when it comes out a pixel short
-    (S/model.py:150-151); this wrapper keeps every pixel on the exact aligned path instead and only the <= 7 mirrored
-    rows / columns of context differ.  Masks are frame-level maps that the model resizes to the (padded) frame itself."""
+    A frame with even sides that fits one tile runs whole through the model, which follows the reference at any even size
+    (odd deeper levels, the decoder's resize to the skip: S/model.py:150-151, golden case ``evenodd``).  Larger frames
+    need windows on the 8-pixel grid, hence the padding; parity unpinned for those (the reference has no tiling, and at an
+    odd H or W its own forward fails at ``out + residual``): only the <= 7 mirrored rows / columns of context differ from
+    the aligned pipeline.  Masks are frame-level maps that the model resizes to the (padded) frame itself."""
 
     def __init__(self, model, tile: int = 256, halo: int = 16, max_batch: int = 32) -> None:
         self.tiled = TiledRestorer(model, tile, halo, max_batch)
@@ -175,6 +176,8 @@ class AnySizeRestorer:
         ph, pw = (-H) % 8, (-W) % 8
         if ph == 0 and pw == 0:
             return self.tiled(x, cond, masks)
+        if H % 2 == 0 and W % 2 == 0 and H <= self.tiled.tile and W <= self.tiled.tile:
+            return self.tiled.model(x, cond, masks)[0]          # native: the reference's own path for such sizes
         if ph >= H or pw >= W:
             raise ValueError("image too small for reflect padding")
         xp = torch.nn.functional.pad(x.float(), (0, pw, 0, ph), mode="reflect")
