@@ -401,7 +401,9 @@ def test_flash_attn_forced_rescale(ops, prec):
 @pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 128, 128), (2, 20, 8, 32), (1, 4, 1, 1), (1, 8, 12, 10), (1, 4, 2, 4),
                                    (1, 8, 68, 120),    # 68 x 120: level-2 map of a 544 x 960 frame: direct DFT (17 | 68) x mixed radix
                                    (2, 8, 30, 40), (1, 20, 135, 240), (1, 4, 90, 6), (1, 8, 270, 480),   # 2^a 3^b 5^c lines
-                                   (1, 4, 14, 22)])    # 7 | 14, 11 | 22: direct DFT both ways
+                                   (1, 4, 14, 22),     # 7 | 14, 11 | 22: prime-radix butterflies (round 3)
+                                   (1, 8, 112, 56), (2, 4, 28, 26), (1, 4, 49, 154), (1, 4, 13, 7),   # 7^2, 7 * 11 * 2, 13 * 2, L = the prime itself
+                                   (1, 4, 19, 34)])    # 19, 17 | 34: primes above 13 keep the direct DFT
 def test_fft_roundtrip_and_parts(ops, shape):
     b, c, h, w = shape
     g = torch.Generator().manual_seed(9)

@@ -319,10 +319,11 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Lines whose length is 2^a 3^b 5^c but not a power of two (the sub-band maps of 1080p / 720p / VGA-sized frames: 540,
-// 270, 135, 480, 240, 120, 360, 180, 90 ...): the same in-place decimation-in-frequency scheme with a host-chosen radix
-// schedule out of {4, 2, 3, 5}, generic loops instead of the fixed one-butterfly-per-thread mapping.  Before this kernel
-// such lines took the O(L^2) direct DFT (120 points: 15x the work).  Other lengths still do.
+// Lines whose length is 2^a 3^b 5^c 7^d 11^e 13^f but not a power of two (the sub-band maps of 1080p / 720p / VGA-sized
+// frames: 540, 270, 135, 480, 240, 120, 360, 180, 90 ...; of 224-pixel frames: 112, 56, 28): the same in-place
+// decimation-in-frequency scheme with a host-chosen radix schedule out of {4, 2, 3, 5, 7, 11, 13}, generic loops instead
+// of the fixed one-butterfly-per-thread mapping.  Before this kernel such lines took the O(L^2) direct DFT (120 points:
+// 15x the work).  Lengths with a prime factor above 13 still do.
 // ------------------------------------------------------------------------------------------
 #define FFT_MAXST 12
 struct FftSched { int n; int radix[FFT_MAXST]; };
@@ -377,6 +378,26 @@ __global__ void __launch_bounds__(256) fft_linesmr_kernel(FftP p, FftSched sc, i
     // multiply by -i (forward) / +i (inverse): the quarter turn of this transform direction
     auto rot = [&](Cx4 d) { return INV ? Cx4{f4neg(d.i), d.r} : Cx4{d.i, f4neg(d.r)}; };
     auto scl = [&](Cx4 a, float f) { return Cx4{make_float4(a.r.x * f, a.r.y * f, a.r.z * f, a.r.w * f), make_float4(a.i.x * f, a.i.y * f, a.i.z * f, a.i.w * f)}; };
+    // butterfly of a prime radix R (7, 11, 13) as a direct R-point DFT: y_i = (sum_j a_j w_R^(ij)) tw[i w1], with
+    // w_R^m = tw[m L / R] out of the line's own table (R divides L).  R^2 complex products per butterfly; such a factor
+    // occurs once or twice in a line (224-pixel frames: sub-bands of 112 = 4 * 4 * 7), the 2 / 3 / 4 / 5 stages carry the rest.
+    auto prime_bfly = [&](auto r_tag, int base, int st, int w1) {
+        constexpr int R = decltype(r_tag)::value;
+        const int rs = L / R;
+        Cx4 a[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[j] = ldc(base + j * st);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            Cx4 y = a[0];
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                const int m = (i * j) % R;
+                y = m ? cadd(y, cmulw(a[j], twr[m * rs], twi[m * rs])) : cadd(y, a[j]);
+            }
+            stc(base + i * st, i ? cmulw(y, twr[i * w1], twi[i * w1]) : y);
+        }
+    };
     int ns = L;
     for (int stg = 0; stg < sc.n; ++stg) {
         const int r = sc.radix[stg], qs = ns / r, tstep = L / ns;
@@ -402,6 +423,12 @@ __global__ void __launch_bounds__(256) fft_linesmr_kernel(FftP p, FftSched sc, i
                 stc(base, cadd(a0, t1));
                 stc(base + st, cmulw(cadd(t2, t3), twr[w1], twi[w1]));
                 stc(base + 2 * st, cmulw(csub(t2, t3), twr[2 * w1], twi[2 * w1]));
+            } else if (r == 7) {
+                prime_bfly(std::integral_constant<int, 7>{}, base, st, w1);
+            } else if (r == 11) {
+                prime_bfly(std::integral_constant<int, 11>{}, base, st, w1);
+            } else if (r == 13) {
+                prime_bfly(std::integral_constant<int, 13>{}, base, st, w1);
             } else {   // 5
                 const Cx4 a0 = ldc(base), a1 = ldc(base + st), a2 = ldc(base + 2 * st), a3 = ldc(base + 3 * st), a4 = ldc(base + 4 * st);
                 const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
@@ -458,7 +485,7 @@ __global__ void __launch_bounds__(256) fft_linesmr_kernel(FftP p, FftSched sc, i
     }
 }
 
-// radix schedule for L = 2^a 3^b 5^c (4s first, then a 2, then 3s and 5s); n = 0 if L has another prime factor
+// radix schedule for L = 2^a 3^b 5^c 7^d 11^e 13^f (4s first, then a 2, then the odd primes); n = 0 if L has another prime factor
 static FftSched fft_schedule(int L) {
     FftSched s = {};
     int v = L;
@@ -466,6 +493,8 @@ static FftSched fft_schedule(int L) {
     while (v % 2 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 2; v /= 2; }
     while (v % 3 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 3; v /= 3; }
     while (v % 5 == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = 5; v /= 5; }
+    for (int pr : {7, 11, 13})
+        while (v % pr == 0 && s.n < FFT_MAXST) { s.radix[s.n++] = pr; v /= pr; }
     if (v != 1) s.n = 0;
     return s;
 }
