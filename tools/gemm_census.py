@@ -1,6 +1,6 @@
 """Per-shape census of the 1x1 / conv GEMM calls of one student step (B=16, 256x256, bf16): for each distinct
 (M, N, K, A dtype, out dtype, epilogue) the call count, time, TFLOP/s and algorithmic GB/s (A + out + residual/blend
-streams).   python tools/gemm_census.py [batch]"""
+streams).   python tools/gemm_census.py [batch] [serial]"""
 import os
 import sys
 from collections import OrderedDict
@@ -12,11 +12,13 @@ from underwater_image_restoration_amd import ops  # noqa: E402
 from underwater_image_restoration_amd.student import NAFNetWFIGate  # noqa: E402
 from underwater_image_restoration_amd.synth import student_param_shapes, synth_state_dict, synth_student_inputs  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 MK = dict(base_channels=64, num_levels=3, blocks_per_level=2, cond_dim=512, num_masks=10, num_degradation_types=10)
 model = NAFNetWFIGate(**MK, precision="bf16")
 model.load_state_dict(synth_state_dict(student_param_shapes(**MK), seed=0))
 model = model.cuda().eval()
+if "serial" in sys.argv:      # SFFB on the main stream: a call's time is its own
+    model.overlap_branches = False
 x, z, m = synth_student_inputs(B, 256, 256, 512, 10, mask_hw=(7, 7), seed=1)
 x, z, m = x.cuda(), z.cuda(), m.cuda()
 for _ in range(2):
