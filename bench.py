@@ -115,6 +115,10 @@ def _op_work(name: str, a: tuple, k: dict):
         gi, hf, B, h, w, C, out = a[0], a[5], a[6], a[7], a[8], a[9], a[10]
         # gate row + hf row in, alpha + four output pixels out (csrc/gate.hip)
         return "WFIGate + idwt2 (fused)", "byte", float(B * h * w) * (gi.shape[1] * 4 + 3 * C * _esz(hf) + C * 4 + 4 * C * _esz(out))
+    if name == "gate_blend":
+        gi, B, h, w, C, merged = a[0], a[5], a[6], a[7], a[8], a[10]
+        # gate row in, alpha + merged out: the block-to-block form (no idwt2, no dwt2 in the next block)
+        return "WFIGate blend (block -> block, no transform)", "byte", float(B * h * w) * (gi.shape[1] * 4 + C * 4 + C * _esz(merged))
     if name == "ffn_fused":
         x, B, n, C, out = a[0], a[5], a[6], a[7], a[8]
         return "WTB FFN (fused ffn.0 -> GELU -> ffn.2 + residual)", "flop", 2.0 * B * n * C * (2 * C) * 2

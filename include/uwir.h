@@ -87,6 +87,12 @@ int uwir_gate_idwt_supported(int C, int Kg);
 int uwir_gate_idwt(const float* gate_in, int ldg, int Kg, const void* w1, const void* w2, const float* bias1, const float* b2,
                    const void* hf, int ld_hf, int B, int h, int w, int C, void* out, int ldo, float* alpha, float* merged,
                    uwir_stream_t stream);
+/* The same gate WITHOUT the inverse transform, for a block that is followed by another block of the same stage
+ * (S/model.py:40 then :31 of the next block): dwt2(idwt2(merged, lh, hl, hh)) returns (merged, lh, hl, hh) up to the factor
+ * 4 fl32(2^-1/2)^4 = 1 - 1.2e-7, so the next block takes merged (written here as bf16 rows, pixel stride ld_merged) as its
+ * ll and keeps the hf rows it already holds; the full-resolution map is never formed.  alpha as above. */
+int uwir_gate_blend(const float* gate_in, int ldg, int Kg, const void* w1, const void* w2, const float* bias1, const float* b2,
+                    int B, int h, int w, int C, float* alpha, void* merged_bf16, int ld_merged, uwir_stream_t stream);
 
 /* ---- S/wtb.py:117-124 the WTB's feed-forward block in one pass (bf16 mode) -----------------------------------------
  *   out = W2 gelu(W0_b x + bias0_b) + b2 + x                 (exact erf GELU, as nn.GELU())

@@ -1107,6 +1107,13 @@ def test_gate_idwt_fused_against_the_three_launches(ops, case):
     ops.gate_idwt(gi, w1c, w2c, bb, b2c, hf, B, h, w, C, out2[:, :C], alpha2, None)
     assert torch.equal(out2, out1) and torch.equal(alpha2, alpha1)
     assert not ops.gate_idwt_supported(48, 96 + 16) and ops.gate_idwt_supported(64, 128)
+    # blend-only form (uwir_gate_blend: a block followed by another block of its stage): the same alpha, and merged as the
+    # bf16 rounding of the very values the fused form blends -- bit for bit, strided destination
+    alpha3 = torch.empty_like(alpha1)
+    m16 = torch.full((M, C + 8), 7.0, device="cuda", dtype=bf)
+    ops.gate_blend(gi, w1c, w2c, bb, b2c, B, h, w, C, alpha3, m16[:, :C])
+    assert torch.equal(alpha3, alpha1) and torch.equal(m16[:, :C], merged1.to(bf))
+    assert float(m16[:, C:].float().min()) == 7.0 and float(m16[:, C:].float().max()) == 7.0
 
 
 @pytest.mark.parametrize("case", [(192, 3, 512), (384, 2, 384)])

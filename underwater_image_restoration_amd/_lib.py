@@ -111,6 +111,7 @@ _SIGS = {
     "uwir_ffn_fused_supported": (ci, [ci, ci]),
     "uwir_ffn_fused": (ci, [vp, ci, vp, C.c_longlong, vp, vp, vp, ci, ci, ci, vp, ci, vp]),
     "uwir_gate_idwt": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp, vp]),
+    "uwir_gate_blend": (ci, [vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
     "uwir_fold_affine_weights": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "uwir_tail_conv3x3_split": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, ci, ci, vp]),
     "uwir_image_metrics_workspace_bytes": (sz, [ci, ci, ci, ci]),

@@ -49,6 +49,8 @@ struct GateP {
     bf16_t* out;             // [B, 2h, 2w, ldo]
     float* alpha;            // [M, C]
     float* merged;           // [M, C] or null
+    bf16_t* merged16;        // blend-only form (out == null): merged as bf16 rows [M, ld_m16]
+    int ld_m16;
     int ldg, ld_hf, ldo, M, n, h, w, tiles, waves_total;
 };
 
@@ -133,6 +135,7 @@ __global__ void __launch_bounds__((GateCfg<CC, MP>::NW * 64)) gate_idwt_kernel(G
             }
         }
 
+        const bool inverse = p.out != nullptr;                   // block-uniform: false = blend-only form (no idwt2)
         // ---- alpha, blend, inverse Haar, 64 channels (4 MFMA tiles) at a time; this lane: channels 16 j + 4 fq .. + 3 of
         // pixel fr.  Results leave through the wave's LDS region as whole rows: direct stores from this layout are 32-byte
         // (out) and 64-byte (alpha) pieces of a line per lane group, and ran the output at 1.9 TB/s.
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__((GateCfg<CC, MP>::NW * 64)) gate_idwt_kernel(G
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int orow = tile * 16 + (lane >> 3) + 8 * u;
-            olive[u] = orow < p.M;
+            olive[u] = inverse && orow < p.M;
             const int q = olive[u] ? orow : p.M - 1;
             const int ob = q / p.n, pix = q - ob * p.n, y = pix / p.w, x = pix - y * p.w;
             obase[u] = p.out + (((size_t)ob * 2 * p.h + 2 * y) * (2 * p.w) + 2 * x) * p.ldo + (lane & 7) * 8;
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__((GateCfg<CC, MP>::NW * 64)) gate_idwt_kernel(G
                 const int c = 64 * g + 16 * j + 4 * fq;
                 t[j] = *reinterpret_cast<const float4*>(grow + c);
                 f[j] = *reinterpret_cast<const float4*>(grow + CC + c);
-                vlh[j] = load4(hrow + c); vhl[j] = load4(hrow + CC + c); vhh[j] = load4(hrow + 2 * CC + c);
+                if (inverse) { vlh[j] = load4(hrow + c); vhl[j] = load4(hrow + CC + c); vhh[j] = load4(hrow + 2 * CC + c); }
             }
             float4 m[4];
 #pragma unroll
@@ -186,6 +189,20 @@ __global__ void __launch_bounds__((GateCfg<CC, MP>::NW * 64)) gate_idwt_kernel(G
                 if (arow < p.M) *reinterpret_cast<float4*>(p.alpha + (size_t)arow * CC + 64 * g + (lane & 15) * 4) = v;
             }
             __builtin_amdgcn_wave_barrier();
+            if (!inverse) {
+                // blend-only: merged as bf16, 16 rows x 128 bytes through the same region, 8 lanes per row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store4(reinterpret_cast<bf16_t*>(stg + fr * SO) + 16 * j + 4 * fq, m[j]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int r = (lane >> 3) + 8 * k, mrow = tile * 16 + r;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * SO + (lane & 7) * 16);
+                    if (mrow < p.M) *reinterpret_cast<bf16x8*>(p.merged16 + (size_t)mrow * p.ld_m16 + 64 * g + (lane & 7) * 8) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             // out: staged row 16 v + fr = output pixel (2y + v / 2, 2x + v % 2) of sub-band pixel fr, 64 channels as bf16
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -242,8 +259,34 @@ extern "C" int uwir_gate_idwt(const float* gate_in, int ldg, int Kg, const void*
                (((uintptr_t)hf & 7) | ((uintptr_t)out & 15)) == 0 && ldo % 8 == 0, "gate_idwt: misaligned pointer or ldo %% 8 != 0");
     GateP p;
     p.gin = gate_in; p.w1 = (const bf16_t*)w1; p.w2 = (const bf16_t*)w2; p.bias1 = bias1; p.b2 = b2;
-    p.hf = (const bf16_t*)hf; p.out = (bf16_t*)out; p.alpha = alpha; p.merged = merged;
+    p.hf = (const bf16_t*)hf; p.out = (bf16_t*)out; p.alpha = alpha; p.merged = merged; p.merged16 = nullptr; p.ld_m16 = 0;
     p.ldg = ldg; p.ld_hf = ld_hf; p.ldo = ldo; p.M = B * h * w; p.n = h * w; p.h = h; p.w = w;
+    p.tiles = ceil_div(p.M, 16);
+    hipStream_t st = (hipStream_t)stream;
+    const bool masks = Kg != 2 * C;
+    if (C == 64) return masks ? gate_launch<64, 16>(p, st) : gate_launch<64, 0>(p, st);
+    if (C == 128) return masks ? gate_launch<128, 16>(p, st) : gate_launch<128, 0>(p, st);
+    return masks ? gate_launch<256, 16>(p, st) : gate_launch<256, 0>(p, st);
+}
+
+// Blend-only form: alpha and merged, no inverse transform.  Between two blocks of one stage the reference runs idwt2 and then
+// the next block's dwt2 on its result (S/model.py:40, :31), which returns (merged, lh, hl, hh) again up to the factor
+// 4 fl32(2^-1/2)^4 = 1 - 1.2e-7: the student (bf16 mode) hands the next block merged (bf16 rows, here) and the hf rows it
+// already holds, and neither the full-resolution map nor its transform touch HBM.  Same kernel, same blend expressions.
+extern "C" int uwir_gate_blend(const float* gate_in, int ldg, int Kg, const void* w1, const void* w2, const float* bias1,
+                               const float* b2, int B, int h, int w, int C, float* alpha, void* merged_bf16, int ld_merged,
+                               uwir_stream_t stream) {
+    UWIR_CHECK(gate_in && w1 && w2 && bias1 && b2 && alpha && merged_bf16, "gate_blend: null pointer");
+    UWIR_CHECK(uwir_gate_idwt_supported(C, Kg), "gate_blend: C = %d, Kg = %d is not a built shape (C in {64, 128, 256}, Kg = 2 C or 2 C + 16)", C, Kg);
+    UWIR_CHECK(B > 0 && h > 0 && w > 0 && (long long)B * h * w < 0x7fffffffLL, "gate_blend: bad shape B=%d h=%d w=%d", B, h, w);
+    UWIR_CHECK(ldg >= Kg && ldg % 4 == 0 && ld_merged >= C && ld_merged % 8 == 0, "gate_blend: bad strides");
+    UWIR_CHECK((((uintptr_t)gate_in | (uintptr_t)bias1 | (uintptr_t)b2 | (uintptr_t)alpha | (uintptr_t)merged_bf16) & 15) == 0,
+               "gate_blend: misaligned pointer");
+    GateP p;
+    p.gin = gate_in; p.w1 = (const bf16_t*)w1; p.w2 = (const bf16_t*)w2; p.bias1 = bias1; p.b2 = b2;
+    p.hf = (const bf16_t*)merged_bf16;   // never read in this form (a valid address keeps the row pointer arithmetic defined)
+    p.out = nullptr; p.alpha = alpha; p.merged = nullptr; p.merged16 = (bf16_t*)merged_bf16; p.ld_m16 = ld_merged;
+    p.ldg = ldg; p.ld_hf = 0; p.ldo = 0; p.M = B * h * w; p.n = h * w; p.h = h; p.w = w;
     p.tiles = ceil_div(p.M, 16);
     hipStream_t st = (hipStream_t)stream;
     const bool masks = Kg != 2 * C;

@@ -137,6 +137,26 @@ def gate_idwt(gate_in: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, bias1: 
                                   _p(out), _ld(out), _p(alpha), _p(merged), _stream(gate_in)), "gate_idwt")
 
 
+def gate_blend(gate_in: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, bias1: torch.Tensor, b2: torch.Tensor,
+               B: int, h: int, w: int, C: int, alpha: torch.Tensor, merged: torch.Tensor) -> None:
+    """WFIGate without idwt2 (a block followed by another block of its stage): alpha fp32, merged as bf16 rows."""
+    _f32(gate_in, bias1, b2, alpha)
+    bf = torch.bfloat16
+    if w1.dtype != bf or w2.dtype != bf or merged.dtype != bf:
+        raise ValueError("gate_blend: w1, w2 and merged must be bf16")
+    Kg = gate_in.shape[1]
+    if tuple(w1.shape) != (64, Kg) or tuple(w2.shape) != (C, 64) or not w1.is_contiguous() or not w2.is_contiguous():
+        raise ValueError("gate_blend: w1 must be [64, Kg] and w2 [C, 64], contiguous")
+    M = B * h * w
+    if gate_in.shape[0] != M or merged.shape[0] != M or merged.shape[1] < C:
+        raise ValueError("gate_blend: row counts do not match B * h * w")
+    if alpha.numel() != M * C or not alpha.is_contiguous() or tuple(bias1.shape) != (B, 64) or not bias1.is_contiguous():
+        raise ValueError("gate_blend: alpha must be a contiguous [B, h, w, C] and bias1 a contiguous [B, 64]")
+    lib = _lib.load()
+    _lib.check(lib.uwir_gate_blend(_p(gate_in), _ld(gate_in), Kg, _p(w1), _p(w2), _p(bias1), _p(b2), B, h, w, C, _p(alpha),
+                                   _p(merged), _ld(merged), _stream(gate_in)), "gate_blend")
+
+
 def ffn_fused_supported(C: int, n: int) -> bool:
     return bool(_lib.load().uwir_ffn_fused_supported(C, n))
 
@@ -613,6 +633,6 @@ def _census_wrap(name: str, fn):
 for _n in ("dwt2", "idwt2", "ln2d_affine", "conv_gemm", "dwconv_ms", "flash_attn", "fft2_amp_phase", "ifft2_polar_add",
            "affine_cast", "stem_conv3x3", "head_conv3x3", "sde_euler_step", "sde_posterior_step", "linear_attention",
            "ln_rows", "groupnorm_affine", "geglu", "linattn_block", "tail_conv3x3", "unet_input", "bilinear_nchw_to_nhwc", "linear",
-           "gate_idwt", "ffn_fused", "fold_affine_weights"):
+           "gate_idwt", "gate_blend", "ffn_fused", "fold_affine_weights"):
     globals()[_n] = _census_wrap(_n, globals()[_n])
 del _n

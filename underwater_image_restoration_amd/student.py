@@ -70,7 +70,8 @@ class NAFNetWFIGate(nn.Module):
         self.overlap_branches = True        # False: every kernel of a forward on the caller's stream, in program order
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
         self.fold_norms = True              # bf16: LayerNorm2d affines folded into per-image weight panels (see _wfi_block)
-        self.fuse_gate = True               # bf16: WFIGate + idwt2 in one launch (ops.gate_idwt); False keeps the three launches
+        self.fuse_gate = True
+        self.chain_blocks = True     # blocks of one stage hand over (merged, hf) instead of idwt2 -> dwt2 (bf16 mode)               # bf16: WFIGate + idwt2 in one launch (ops.gate_idwt); False keeps the three launches
         self.fuse_ffn = True                # bf16, folded norms: ffn.0 -> GELU -> ffn.2 + residual in one launch (ops.ffn_fused)
         self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
 
@@ -291,23 +292,27 @@ class NAFNetWFIGate(nn.Module):
         return lf, spatial
 
     # ------------------------------------------------------------------ one WFI block
-    def _wfi_block(self, bp: dict, x_in: torch.Tensor, B: int, h2: int, w2: int, cond_all: torch.Tensor,
-                   gate_in: torch.Tensor, out: torch.Tensor, lvl: int, taps: Optional[dict]) -> torch.Tensor:
+    def _wfi_block(self, bp: dict, x_in: Optional[torch.Tensor], B: int, h2: int, w2: int, cond_all: torch.Tensor,
+                   gate_in: torch.Tensor, out: Optional[torch.Tensor], lvl: int, taps: Optional[dict]) -> torch.Tensor:
         """x_in: [B*h2*w2, ld] view with C channels; writes out ([B*2h*2w, ld'] view, h = h2 // 2, w = w2 // 2: an odd
-        input side loses its last row / column in dwt2, dwt_fft.py:38); returns alpha [B,h,w,C]."""
+        input side loses its last row / column in dwt2, dwt_fft.py:38); returns alpha [B,h,w,C].
+        Chained blocks (bf16 mode, ``chain_blocks``): ``out=None`` leaves merged in the level's ll buffer and the block's hf
+        rows where they are instead of forming idwt2's map, and ``x_in=None`` makes the next block start from those
+        (dwt2 of idwt2 is the identity up to 1.2e-7, see uwir_gate_blend in include/uwir.h)."""
         Cc = bp["C"]
         Cw = 3 * Cc
         h, w = h2 // 2, w2 // 2
         n = h * w
         Mr = B * n
-        dev, f32, adt = x_in.device, torch.float32, self._pack["adt"]
+        dev, f32, adt = gate_in.device, torch.float32, self._pack["adt"]
         tg = f"L{lvl}"
         buf = lambda name, cols, dt=f32, zero=False: self._buf(tg + name, Mr, cols, dt, dev, zero)  # noqa: E731
         small = lambda name, cols: self._buf(tg + name, B, cols, f32, dev)  # noqa: E731
         # bf16 mode: the sub-band stream (ll, hf, x1, the block's hf output) is bf16 -- these rows are read by LayerNorm
         # statistics, the norm-and-cast pass, residual epilogues and the inverse transform, all HBM-bound; sums stay fp32
         ll, hf = buf("ll", Cc, adt), buf("hf", Cw, adt)
-        ops.dwt2(x_in, B, h2, w2, Cc, ll, hf)
+        if x_in is not None:
+            ops.dwt2(x_in, B, h2, w2, Cc, ll, hf)
         ws = self._buf("lnws", 1, max(ops.ln2d_workspace_bytes(B, n, Cw) // 8, 1), torch.float64, dev)
 
         # The SFFB branch (on ll) and the WTB branch (on hf) are independent until the CFC: SFFB (FFT passes, C-wide 1x1
@@ -406,6 +411,9 @@ class NAFNetWFIGate(nn.Module):
         alpha = torch.empty(B, h, w, Cc, dtype=f32, device=dev)
         # bf16: gate MLP, blend and the inverse transform in one launch (csrc/gate.hip): the hidden rows, the merged rows
         # and the second read of t / f never reach HBM (3.0 -> 1.7 KB per sub-band pixel at C = 64)
+        if out is None:     # chained: the next block of this stage reads merged (-> ll) and hf_out (= hf) in place
+            ops.gate_blend(gate_in, bp["g1_w"], bp["g2_w"], bb, bp["g2_b"], B, h, w, Cc, alpha, ll)
+            return alpha
         fused_gate = bf and self.fuse_gate and out.dtype == torch.bfloat16 and ops.gate_idwt_supported(Cc, Kg)
         if fused_gate:
             merged = buf("merged", Cc) if taps is not None else None
@@ -512,6 +520,7 @@ class NAFNetWFIGate(nn.Module):
         def run_stage(prefix: str, lvl: int, cur: torch.Tensor, final_out: Optional[torch.Tensor],
                       in_size: Tuple[int, int]) -> torch.Tensor:
             Hl, Wl = size[lvl]
+            chained = False
             for bi in range(self.blocks_per_level):
                 last = bi == self.blocks_per_level - 1
                 if last and final_out is not None:
@@ -520,8 +529,13 @@ class NAFNetWFIGate(nn.Module):
                     dst = (feat[lvl][1] if cur.data_ptr() == feat[lvl][0].data_ptr() else feat[lvl][0])[:B * Hl * Wl]
                 bt = {} if taps is not None else None
                 hb, wb_ = in_size if bi == 0 else (Hl, Wl)     # only a stage's first block can see an odd side
-                a = self._wfi_block(pk["blocks"][f"{prefix}.blocks.{bi}."], cur, B, hb, wb_, cond_all, gate_in[lvl],
-                                    dst, lvl, bt)
+                # bf16 mode: a block followed by another block of the stage hands over (merged, hf) instead of idwt2's map
+                chain_out = (not last and taps is None and self.chain_blocks and self.fuse_gate
+                             and pk["adt"] == torch.bfloat16
+                             and ops.gate_idwt_supported(ch[lvl], gate_in[lvl].shape[1]))
+                a = self._wfi_block(pk["blocks"][f"{prefix}.blocks.{bi}."], None if chained else cur, B, hb, wb_, cond_all,
+                                    gate_in[lvl], None if chain_out else dst, lvl, bt)
+                chained = chain_out
                 alphas.append(a.permute(0, 3, 1, 2))
                 if self.on_block is not None:
                     self.on_block(len(alphas))     # pipeline.DualReplicaRestorer staggers its second stream on this
