@@ -90,12 +90,15 @@ def test_student_bf16_psnr(name):
     assert p >= 60.0
 
 
+@pytest.mark.parametrize("attr", ["chain_blocks", "compose_reproj"])
 @pytest.mark.parametrize("name", ["full32", "evenodd"])
-def test_student_bf16_chained_blocks_against_the_transform_round_trip(name):
-    """bf16 mode hands (merged, hf) from a block to the next block of its stage instead of idwt2 -> HBM -> dwt2
-    (uwir_gate_blend; dwt2 of idwt2 is the identity up to 1.2e-7 in the reference's fp32 taps).  The chained forward must
-    agree with the unchained one to bf16 noise (the unchained stream rounds the full-resolution map to bf16 once more) and
-    be at least as close to the reference's fp64 output."""
+def test_student_bf16_algebraic_shortcuts_against_the_plain_forms(name, attr):
+    """Two shortcuts of bf16 mode that are identities in exact arithmetic, each against the forward without it:
+    chain_blocks -- a block hands (merged, hf) to the next block of its stage instead of idwt2 -> HBM -> dwt2
+    (uwir_gate_blend; dwt2 of idwt2 is the identity up to 1.2e-7 in the reference's fp32 taps; the plain stream rounds the
+    full-resolution map to bf16 once more);  compose_reproj -- SFFB's reproj conv and the CFC's k / vf convs (sffb.py:55,
+    cfc.py:26-28: nothing in between) run as one 1x1 conv with weights multiplied in fp64 at load time.
+    Each must agree with the plain forward to bf16 noise and be about as close to the reference's fp64 output."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     cfg, mk, sd, x, z, m = student_case_setup(name)[:6]
@@ -103,13 +106,13 @@ def test_student_bf16_chained_blocks_against_the_transform_round_trip(name):
     ref = torch.from_numpy(gold["out_f64"])
     model = _model(mk, sd, "bf16")
     args = (x.cuda(), z.cuda(), None if m is None else m.cuda())
-    assert model.chain_blocks
+    assert getattr(model, attr)
     out_c, al_c, _ = model(*args)
-    model.chain_blocks = False
+    setattr(model, attr, False)
     out_u, al_u, _ = model(*args)
     out_c, out_u = out_c.cpu(), out_u.cpu()
     pc, pu, pcu = psnr(out_c, ref), psnr(out_u, ref), psnr(out_c, out_u.double())
-    print(f"\n[{name}/bf16] chained {pc:.2f} dB, unchained {pu:.2f} dB against the reference; chained vs unchained {pcu:.2f} dB")
+    print(f"\n[{name}/bf16] {attr}: on {pc:.2f} dB, off {pu:.2f} dB against the reference; on vs off {pcu:.2f} dB")
     assert pcu >= 55.0 and pc >= pu - 1.0
     assert len(al_c) == len(al_u) and all(a.shape == b.shape for a, b in zip(al_c, al_u))
 

@@ -71,6 +71,7 @@ class NAFNetWFIGate(nn.Module):
         self.on_block = None                # optional callable(block_count), called after every WFI block is enqueued
         self.fold_norms = True              # bf16: LayerNorm2d affines folded into per-image weight panels (see _wfi_block)
         self.fuse_gate = True
+        self.compose_reproj = True   # SFFB's last 1x1 conv composed with the CFC's k / vf convs (bf16 mode, no taps)
         self.chain_blocks = True     # blocks of one stage hand over (merged, hf) instead of idwt2 -> dwt2 (bf16 mode)               # bf16: WFIGate + idwt2 in one launch (ops.gate_idwt); False keeps the three launches
         self.fuse_ffn = True                # bf16, folded norms: ffn.0 -> GELU -> ffn.2 + residual in one launch (ops.ffn_fused)
         self.supports_windows = True        # forward(..., windows=...): halo windows read / written in place (tiling.py)
@@ -203,6 +204,11 @@ class NAFNetWFIGate(nn.Module):
             b["kvf_w"] = torch.cat([sd[f + "k_conv.weight"].reshape(Cc, Cc), sd[f + "vf_conv.weight"].reshape(Cc, Cc)],
                                    dim=0).to(wdt).contiguous()
             b["kvf_b"] = torch.cat([vec(sd[f + "k_conv.bias"]), vec(sd[f + "vf_conv.bias"])]).contiguous()
+            # k_conv / vf_conv act on lf = reproj(sf) with nothing in between (sffb.py:55, cfc.py:26-28): composed in fp64,
+            # [k | vf] (reproj sf + b_r) + b = ([k | vf] reproj) sf + ([k | vf] b_r + b); used when lf itself is not asked for
+            wkv = torch.cat([sd[f + "k_conv.weight"].reshape(Cc, Cc), sd[f + "vf_conv.weight"].reshape(Cc, Cc)], dim=0).double()
+            b["kvfr_w"] = (wkv @ sd[l + "reproj.weight"].reshape(Cc, Cc).double()).to(wdt).contiguous()
+            b["kvfr_b"] = (wkv @ sd[l + "reproj.bias"].double() + b["kvf_b"].double()).to(f32).contiguous()
             g = p + "gate."
             b["cp"] = add_cond(sd[g + "cond_proj.weight"], sd[g + "cond_proj.bias"])
             w0 = sd[g + "net.0.weight"].reshape(64, -1)  # columns [hf | lf | cond | masks], wfi_gate.py:37-42
@@ -262,9 +268,11 @@ class NAFNetWFIGate(nn.Module):
             self._streams[dev] = st
         return st
 
-    def _sffb(self, bp: dict, ll: torch.Tensor, B: int, h: int, w: int, cond_all: torch.Tensor, lvl: int):
+    def _sffb(self, bp: dict, ll: torch.Tensor, B: int, h: int, w: int, cond_all: torch.Tensor, lvl: int,
+              want_lf: bool = True):
         """SpatialFrequencyFusionBlock (sffb.py:44-55) on ll -> (lf, spatial).  Touches only buffers of its own (its
-        LayerNorm workspace included), so it may run on another stream than the WTB branch."""
+        LayerNorm workspace included), so it may run on another stream than the WTB branch.  ``want_lf=False`` returns
+        the rows BEFORE the last 1x1 conv (reproj) in place of lf: the caller applies reproj composed with its own conv."""
         Cc = bp["C"]
         n, Mr = h * w, B * h * w
         dev, f32, adt = ll.device, torch.float32, self._pack["adt"]
@@ -287,6 +295,8 @@ class NAFNetWFIGate(nn.Module):
         ops.conv_gemm(ph, bp["ph_w"], ph2, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["ph_b"])
         sf = amp  # amp is dead: reuse
         ops.ifft2_polar_add(amp2, ph2, spatial, B, h, w, Cc, sf, fws)
+        if not want_lf:
+            return sf, spatial
         lf = buf("lf", Cc)
         ops.conv_gemm(sf, bp["reproj_w"], lf, B=B, H=h, W=w, C_=Cc, N=Cc, bias=bp["reproj_b"])
         return lf, spatial
@@ -320,11 +330,14 @@ class NAFNetWFIGate(nn.Module):
         # step, bit-identical.  (Releasing it exactly at the attention launch, to hide it in the shadow of that
         # exp-bound kernel, gains the same 0.6 ms but slows the attention launch itself by 2 %: its blocks fill the
         # register file, so foreign workgroups only get in as its rounds retire.)
+        # bf16 mode without taps: lf = reproj(sf) is only ever read by the CFC's k / vf convs, so the two 1x1 convs run as one
+        # (weights composed at load time) and the fp32 lf rows are never written
+        want_lf = not (adt == torch.bfloat16 and taps is None and self.compose_reproj)
         side = self._side_stream(dev) if self.overlap_branches else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dev))   # ll / hf of THIS block are written
             with torch.cuda.stream(side):
-                lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl)
+                lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl, want_lf)
                 sffb_done = torch.cuda.Event()
                 sffb_done.record(side)
 
@@ -393,12 +406,15 @@ class NAFNetWFIGate(nn.Module):
         if side is not None:
             torch.cuda.current_stream(dev).wait_event(sffb_done)
         else:
-            lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl)
+            lf, spatial = self._sffb(bp, ll, B, h, w, cond_all, lvl, want_lf)
 
         # ---------------- CrossFrequencyConditioner (cfc.py:24-39)
         qvt, kvf = buf("qvt", 2 * Cc, adt), buf("kvf", 2 * Cc, adt)
         ops.conv_gemm(hf_out, bp["qvt_w"], qvt, B=B, H=h, W=w, C_=Cw, N=2 * Cc, bias=bp["qvt_b"], col_scale=bp["qvt_cs"])
-        ops.conv_gemm(lf, bp["kvf_w"], kvf, B=B, H=h, W=w, C_=Cc, N=2 * Cc, bias=bp["kvf_b"])
+        if want_lf:
+            ops.conv_gemm(lf, bp["kvf_w"], kvf, B=B, H=h, W=w, C_=Cc, N=2 * Cc, bias=bp["kvf_b"])
+        else:
+            ops.conv_gemm(lf, bp["kvfr_w"], kvf, B=B, H=h, W=w, C_=Cc, N=2 * Cc, bias=bp["kvfr_b"])
         hd2 = Cc // 4
         ops.flash_attn(qvt[:, :Cc], kvf[:, :Cc], qvt[:, Cc:], kvf[:, Cc:], B, n, 4, hd2, 0.0,
                        gate_in[:, :Cc], gate_in[:, Cc:2 * Cc])
