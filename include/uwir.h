@@ -43,7 +43,7 @@ int uwir_version(void);
  * (N % 288 == 0: the 256 x 192 one where N % 192 == 0, else 128 x 128; same sums in the same order). */
 void uwir_conv_variant(int variant);
 /* Measurement hook with no counterpart in the reference: the 256 x 288 large-K bf16 GEMM (out[M, N] = A[M, K] Wt[N, K]^T + bias,
- * dense rows; N % 288 == 0, K % 64 == 0, K >= 1024, M >= 4096) or one of its timing-only ablations, which leave `out`
+ * dense rows; N % 288 == 0, K % 64 == 0, K >= 192, M >= 4096) or one of its timing-only ablations, which leave `out`
  * undefined: 0 = the kernel as uwir_conv_gemm launches it, 1 = every wave issues its LDS-DMA right after the stage barrier,
  * 2 = every wave between the two k-halves, 3 = no MFMAs, 4 = no LDS-DMA inside the K loop, 5 = the LDS-DMA fill alone. */
 int uwir_gemm_wide_probe(const void* A, const void* Wt, void* out, const float* bias, int M, int N, int K, int variant,

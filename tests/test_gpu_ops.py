@@ -1333,7 +1333,8 @@ def test_unet_stem_7x7_mfma(ops):
     assert float((out[:, n:].float() - o32).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("shape", [(3, 256, 192, 576), (2, 128, 64, 128), (16, 1024, 768, 1536)])
+@pytest.mark.parametrize("shape", [(3, 256, 192, 576), (2, 128, 64, 128), (16, 1024, 768, 1536),
+                                   (16, 1024, 192, 576), (8, 512, 768, 2304), (5, 1280, 384, 1152)])   # the 256 x 288 kernel (round 3)
 def test_fold_affine_weights_and_batched_gemm(ops, shape):
     """LayerNorm2d's per-image affine folded into the next 1x1 conv (S/utils.py:18-36 -> S/wtb.py:50,71):
     W (a_b x + s_b) + bias == (W diag(a_b)) x + (W s_b + bias), with per-image bf16 weight panels in the LDS-DMA GEMM."""
@@ -1356,6 +1357,15 @@ def test_fold_affine_weights_and_batched_gemm(ops, shape):
     # exact restatement on the bf16 panels: only the accumulation order and the output rounding remain
     ref2 = F.gelu(torch.einsum("bnk,bok->bno", x.double().reshape(b, n, k), Wb.double().cpu()) + bb.double().cpu()[:, None])
     assert rel(out.reshape(b, n, nn), ref2) < 5e-3
+    if nn % 288 == 0 and b * n >= 4096:   # taken by the 256 x 288 kernel: against the 128 x 128 LDS-DMA kernel (variant bit 6)
+        lib = ops._lib.load()
+        out2 = torch.empty_like(out)
+        lib.uwir_conv_variant(64)
+        try:
+            ops.conv_gemm(x.cuda(), Wb, out2, B=b, H=n // 16, W=16, C_=k, N=nn, batch_bias=bb, act=ops.ACT_GELU, w_batched=True)
+        finally:
+            lib.uwir_conv_variant(0)
+        assert rel(out2.reshape(b, n, nn), ref2) < 5e-3 and float((out.float() - out2.float()).abs().max()) < 0.07
     with pytest.raises(Exception):      # tiles would straddle images
         ops.conv_gemm(x.cuda()[:b * 96], Wb, out[:b * 96], B=b, H=6, W=16, C_=k, N=nn, batch_bias=bb, w_batched=True)
 

@@ -1676,9 +1676,9 @@ static int launch_gemm(const GemmP& p0, hipStream_t stream) {
             return uwir_set_error(UWIR_EUNSUPPORTED, "conv_gemm: w_batch_stride needs a plain bf16 1x1 GEMM (bf16 rows, K %% 64 == 0, "
                                                      "N > 64), OH * OW %% 128 == 0 and a stride >= N * K, a multiple of 8");
     }
-    if (g_gemm_wide && !p.a.w_batch_stride && glds_eligible(p.a, p.K)) {
-        int took = g_gemm_288 ? uwir_gemm_wide288_try(p.a, p.M, p.K, stream) : 0;
-        if (took == 0) took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
+    if (g_gemm_wide && glds_eligible(p.a, p.K)) {
+        int took = g_gemm_288 ? uwir_gemm_wide288_try(p.a, p.M, p.K, stream) : 0;   // (takes per-image weight panels too)
+        if (took == 0 && !p.a.w_batch_stride) took = uwir_gemm_wide_try(p.a, p.M, p.K, stream);
         if (took != 0) return took < 0 ? took : UWIR_OK;
     }
     int bn = p.a.N <= 64 ? 64 : 128;

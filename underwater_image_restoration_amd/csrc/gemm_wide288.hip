@@ -50,7 +50,9 @@ struct Gw3P {
     bf16_t* out;
     const float* bias;
     const float* col_scale;
-    int M, N, K, lda, ldo, act, tiles_n, nblocks;
+    const float* batch_bias;        // per-image bias rows [B, batch_ld] or null
+    long long w_batch_stride;       // elements between the weight panels of consecutive images, 0 = one shared panel
+    int M, N, K, lda, ldo, act, tiles_n, nblocks, rows_per_image, batch_ld;
 };
 
 __device__ __forceinline__ void g3_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
@@ -78,7 +80,9 @@ __global__ void __launch_bounds__(512, 1) gemm_w288_kernel(Gw3P p) {
     // staging: A = 32 pieces (wave w: 4w .. 4w + 3), W = 36 pieces (wave w: 4w .. 4w + 3; waves 0-3 also piece 32 + w);
     // lane -> (row in piece = lane / 8, LDS chunk = lane % 8) reads GLOBAL chunk (lane % 8) ^ (row & 7)
     const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
-    const char* w_base = (const char*)(p.W + (size_t)n0 * K);
+    // per-image weight panels / bias rows (the folded LayerNorm2d affine): a tile lies inside one image (host check)
+    const int img = p.rows_per_image ? m0 / p.rows_per_image : 0;
+    const char* w_base = (const char*)(p.W + (size_t)img * (size_t)p.w_batch_stride + (size_t)n0 * K);
     unsigned a_off[4], w_off[5];
     {
         const int prow = lane >> 3, pch = lane & 7;
@@ -172,7 +176,8 @@ __global__ void __launch_bounds__(512, 1) gemm_w288_kernel(Gw3P p) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const int nl = 16 * j + 4 * fq, n = n0 + wn0 + nl;
-        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.batch_bias) bv += *reinterpret_cast<const f32x4*>(p.batch_bias + (size_t)img * p.batch_ld + n);
         const f32x4 cs = p.col_scale ? *reinterpret_cast<const f32x4*>(p.col_scale + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -198,10 +203,17 @@ __global__ void __launch_bounds__(512, 1) gemm_w288_kernel(Gw3P p) {
 }
 
 static int g3_fill(Gw3P& p, const uwir_gemm_args& g, int M, int K) {
-    if (g.N % G3_BN != 0 || K % G3_BK != 0 || K < 1024 || M < 4096) return 0;
-    if (g.res || g.blend_out || g.blend_t || g.batch_scale || g.batch_bias || g.store_mode != 0 || !g.out || g.a_scale || g.ups ||
-        g.w_batch_stride)
-        return 0;
+    // K >= 1024: the merge GEMMs this kernel was built for.  192 <= K < 1024 (round 3: the WTB's qkv GEMM, three to
+    // twelve stages per tile): measured against the 128 x 128 LDS-DMA kernel at M 262144 N 576 K 192 122 vs 141 us (158 with
+    // per-image panels and bias rows), M 16384 N 2304 K 768 54 vs 65, M 65536 N 1152 K 384 70 vs 70.
+    if (g.N % G3_BN != 0 || K % G3_BK != 0 || K < 192 || M < 4096) return 0;
+    if (g.res || g.blend_out || g.blend_t || g.batch_scale || g.store_mode != 0 || !g.out || g.a_scale || g.ups) return 0;
+    const int rpi = g.OH * g.OW;
+    const int bld = g.batch_ld ? g.batch_ld : g.N;
+    if (g.w_batch_stride || g.batch_bias) {      // per-image operands: whole tiles inside one image, 16-byte aligned rows
+        if (rpi <= 0 || rpi % G3_BM != 0 || M % rpi != 0) return 0;
+        if (g.w_batch_stride % 8 != 0 || g.w_batch_stride < 0 || ((uintptr_t)g.batch_bias & 15) || bld % 4 != 0) return 0;
+    }
     if (g.out_dtype != UWIR_BF16) return 0;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.Wt & 15) || g.lda % 8 != 0 || ((uintptr_t)g.out & 15) || g.ldo % 8 != 0) return 0;
     if (((uintptr_t)g.bias & 15) || ((uintptr_t)g.col_scale & 15)) return 0;
@@ -211,6 +223,10 @@ static int g3_fill(Gw3P& p, const uwir_gemm_args& g, int M, int K) {
     p.out = (bf16_t*)g.out;
     p.bias = g.bias;
     p.col_scale = g.col_scale;
+    p.batch_bias = g.batch_bias;
+    p.w_batch_stride = g.w_batch_stride;
+    p.rows_per_image = (g.w_batch_stride || g.batch_bias) ? rpi : 0;
+    p.batch_ld = bld;
     p.M = M; p.N = g.N; p.K = K; p.lda = g.lda; p.ldo = g.ldo; p.act = g.act;
     p.tiles_n = g.N / G3_BN;
     const long long nb = (long long)ceil_div(M, G3_BM) * p.tiles_n;
@@ -239,7 +255,7 @@ extern "C" int uwir_gemm_wide_probe(const void* A, const void* Wt, void* out, co
     g.A = A; g.Wt = Wt; g.out = out; g.bias = bias; g.N = N; g.lda = K; g.ldo = N; g.out_dtype = UWIR_BF16; g.act = UWIR_ACT_NONE;
     Gw3P p;
     UWIR_CHECK(g3_fill(p, g, M, K), "gemm_wide_probe: M %d N %d K %d is not a shape of the 256 x 288 kernel (N %% 288 == 0, K %% 64 == 0, "
-               "K >= 1024, M >= 4096, 16-byte aligned pointers)", M, N, K);
+               "K >= 192, M >= 4096, 16-byte aligned pointers)", M, N, K);
 #define G3_GO(V) hipLaunchKernelGGL((gemm_w288_kernel<V>), dim3(p.nblocks), dim3(512), 0, (hipStream_t)stream, p)
     switch (variant) {
         case 1: G3_GO(1); break;
