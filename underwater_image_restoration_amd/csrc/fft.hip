@@ -22,6 +22,10 @@ struct FftP {
     int ld_in, ld_out, ld_add;
     int H, W, C, L, CS, logL;
     float norm;
+    int half;          // fft_lines4_kernel only.  Forward (real input): columns 0 .. W/2 of the row pass are kept, the column
+                       // pass transforms those and writes each bin's mirror as its conjugate.  Inverse (real part
+                       // wanted): the column pass transforms the Hermitian part of the spectrum on columns 0 .. W/2,
+                       // the row pass reads the other columns as conjugates
 };
 
 __device__ __forceinline__ int bitrev(int v, int bits) {
@@ -199,23 +203,38 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
         twr[k] = c;
         twi[k] = INV ? s : -s;
     }
+    // column lines of a half spectrum: W/2 + 1 per image (FWD_COLS with p.half), else W
+    const int WL = ((MODE == FFT_FWD_COLS || MODE == FFT_INV_COLS) && p.half) ? p.W / 2 + 1 : p.W;
     auto pixel = [&](int line, int j) -> size_t {
-        const int b = ROWS ? line / p.H : line / p.W, fixed = ROWS ? line % p.H : line % p.W;
+        const int b = ROWS ? line / p.H : line / WL, fixed = ROWS ? line % p.H : line % WL;
         return ROWS ? ((size_t)b * p.H + fixed) * p.W + j : ((size_t)b * p.H + j) * p.W + fixed;
     };
     // ---- load (natural order).  nlb * L == 256 (host), so a thread has exactly 4 (pixel, quad) items: all of their
     // global loads are issued before the first LDS store (a rolled load -> store loop exposes one HBM round trip per item)
-    float4 lr[4], li[4];
+    // Inverse transform whose REAL part is wanted (p.half): Re ifft2(S) = ifft2(Sh), Sh[k] = (S[k] + conj S[-k]) / 2, and
+    // Sh is Hermitian.  The column pass forms Sh for columns 0 .. W/2 only (mr / mi: the mirrored bin ((H - ky) % H,
+    // (W - kx) % W) of the input), the row pass reads column j > W/2 of its line as the conjugate of column W - j.
+    float4 lr[4], li[4], mr[4], mi[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = tid + 256 * it;
         const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
         lr[it] = make_float4(0, 0, 0, 0);
         li[it] = make_float4(0, 0, 0, 0);
+        mr[it] = make_float4(0, 0, 0, 0);
+        mi[it] = make_float4(0, 0, 0, 0);
         if (4 * q < ncs && line < nlines) {
-            const size_t px = pixel(line, j);
+            const bool conj_src = MODE == FFT_INV_ROWS && p.half && j > p.W / 2;
+            const size_t px = pixel(line, conj_src ? p.W - j : j);
             lr[it] = load4(p.in0 + px * p.ld_in + c0 + 4 * q);
             if (MODE != FFT_FWD_ROWS) li[it] = load4(p.in1 + px * p.ld_in + c0 + 4 * q);
+            if (conj_src) li[it] = f4neg(li[it]);
+            if (MODE == FFT_INV_COLS && p.half) {
+                const int b = line / WL, fixed = line % WL;
+                const size_t pm = ((size_t)b * p.H + (j ? p.H - j : 0)) * p.W + (fixed ? p.W - fixed : 0);
+                mr[it] = load4(p.in0 + pm * p.ld_in + c0 + 4 * q);
+                mi[it] = load4(p.in1 + pm * p.ld_in + c0 + 4 * q);
+            }
         }
     }
 #pragma unroll
@@ -230,6 +249,13 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
             sincosf(ph.y, &s, &c); vr.y = a.y * c; vi.y = a.y * s;
             sincosf(ph.z, &s, &c); vr.z = a.z * c; vi.z = a.z * s;
             sincosf(ph.w, &s, &c); vr.w = a.w * c; vi.w = a.w * s;
+            if (p.half) {
+                const float4 a2 = mr[it], p2 = mi[it];
+                sincosf(p2.x, &s, &c); vr.x = 0.5f * (vr.x + a2.x * c); vi.x = 0.5f * (vi.x - a2.x * s);
+                sincosf(p2.y, &s, &c); vr.y = 0.5f * (vr.y + a2.y * c); vi.y = 0.5f * (vi.y - a2.y * s);
+                sincosf(p2.z, &s, &c); vr.z = 0.5f * (vr.z + a2.z * c); vi.z = 0.5f * (vi.z - a2.z * s);
+                sincosf(p2.w, &s, &c); vr.w = 0.5f * (vr.w + a2.w * c); vi.w = 0.5f * (vi.w - a2.w * s);
+            }
         }
         *reinterpret_cast<float4*>(&re[(ll * L + j) * CS + 4 * q]) = vr;
         *reinterpret_cast<float4*>(&im[(ll * L + j) * CS + 4 * q]) = vi;
@@ -288,6 +314,7 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
         const int i = tid + 256 * it;
         const int q = i % Q4, j = (i / Q4) % L, ll = i / (Q4 * L), line = line0 + ll;
         if (4 * q >= ncs || line >= nlines) continue;
+        if (MODE == FFT_FWD_ROWS && p.half && j > p.W / 2) continue;   // X[W - k] = conj X[k]: the column pass restores them
         int pos = 0, kk = j, sz = L;
         while (sz >= 4) { pos += (kk & 3) * (sz >> 2); kk >>= 2; sz >>= 2; }
         if (sz == 2) pos += kk & 1;
@@ -298,7 +325,7 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
         const size_t px = pixel(line, j);
         if (MODE == FFT_FWD_COLS) {
             // bins with ky in {0,H/2} and kx in {0,W/2} of a real signal are exactly real: pin Im = +0
-            const int fixed = line % p.W;
+            const int fixed = line % WL;
             const bool fx_self = fixed == 0 || (p.W % 2 == 0 && fixed == p.W / 2);
             if (fx_self && (j == 0 || (p.H % 2 == 0 && j == p.H / 2))) vi = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 a, ph;
@@ -308,6 +335,14 @@ __global__ void __launch_bounds__(256) fft_lines4_kernel(FftP p, int nlines, int
             a.w = hypotf(vr.w, vi.w); ph.w = atan2f(vi.w, vr.w);
             store4(p.out0 + px * p.ld_out + c0 + 4 * q, a);
             store4(p.out1 + px * p.ld_out + c0 + 4 * q, ph);
+            if (p.half && !fx_self) {
+                // F[(H - ky) % H, W - kx] = conj F[ky, kx] for a real map: same amplitude, phase negated (atan2 is odd in
+                // its first argument, signed zeros included)
+                const int b = line / WL;
+                const size_t pm = ((size_t)b * p.H + (j ? p.H - j : 0)) * p.W + (p.W - fixed);
+                store4(p.out0 + pm * p.ld_out + c0 + 4 * q, a);
+                store4(p.out1 + pm * p.ld_out + c0 + 4 * q, make_float4(-ph.x, -ph.y, -ph.z, -ph.w));
+            }
         } else if (MODE == FFT_INV_ROWS) {
             vr.x += ad[it].x; vr.y += ad[it].y; vr.z += ad[it].z; vr.w += ad[it].w;
             store4(p.out0 + px * p.ld_out + c0 + 4 * q, vr);
@@ -524,7 +559,7 @@ static int launch_fft(FftP p, int B, hipStream_t stream) {
     const bool pow2 = p.logL >= 0;
     p.CS = pick_cs(p.L, pow2);
     p.norm = 1.0f / sqrtf((float)p.L);
-    const int nlines_all = rows ? B * p.H : B * p.W;
+    const int nlines_all = rows ? B * p.H : B * (p.half ? p.W / 2 + 1 : p.W);
     if (pow2 && p.L >= 4 && p.L <= 256 && g_fft_radix4) {
         const int nlb = 256 / p.L;   // nlb * L == 256: one radix-4 butterfly and 4 load / store items per thread
         const size_t lds4 = ((size_t)2 * nlb * p.L * FFT4_CS + 2 * (size_t)p.L) * sizeof(float);
@@ -584,6 +619,9 @@ extern "C" int uwir_fft2_amp_phase(const float* x, int ldx, int B, int H, int W,
     float* wim = wre + (size_t)B * H * W * C;
     FftP p = {};
     p.H = H; p.W = W; p.C = C;
+    // real input: when both passes take the radix-4 line kernel, half of the intermediate spectrum is neither written nor
+    // transformed (Hermitian symmetry); the other line kernels keep the full form
+    p.half = (g_fft_radix4 && ilog2_exact(W) >= 2 && ilog2_exact(H) >= 2 && W <= 256 && H <= 256) ? 1 : 0;
     p.in0 = x; p.in1 = nullptr; p.ld_in = ldx; p.out0 = wre; p.out1 = wim; p.ld_out = C;
     rc = launch_fft<FFT_FWD_ROWS>(p, B, (hipStream_t)stream);
     if (rc) return rc;
@@ -603,6 +641,8 @@ extern "C" int uwir_ifft2_polar_add(const float* amp, const float* phase, int ld
     float* wim = wre + (size_t)B * H * W * C;
     FftP p = {};
     p.H = H; p.W = W; p.C = C;
+    // only the real part of the inverse is kept (sffb.py:54): the Hermitian part of the spectrum on half the columns
+    p.half = (g_fft_radix4 && ilog2_exact(W) >= 2 && ilog2_exact(H) >= 2 && W <= 256 && H <= 256) ? 1 : 0;
     p.in0 = amp; p.in1 = phase; p.ld_in = ld_in; p.out0 = wre; p.out1 = wim; p.ld_out = C;
     rc = launch_fft<FFT_INV_COLS>(p, B, (hipStream_t)stream);
     if (rc) return rc;
