@@ -1295,7 +1295,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_resw_kernel(GemmP p) {
         return r;
     };
     // wave w issues pieces w, w + 4, ..: wave 0 one more than the others (13 pieces)
-    const int my_pieces = (A_PIECES - wave + 3) / 4;
     // DMA of chunk q (tile list position q / NCH) into buffer q % NB; returns the mask of this lane's padding pieces
     auto issue_a = [&](int q) -> unsigned {
         const int t = tile_of(q / NCH), c = q % NCH;
